@@ -1,0 +1,76 @@
+"""ctypes binding of libcer_hip.so (declared in include/cer_hip.h).
+
+There is no CPU fallback: if the shared object is absent or a call fails, a
+RuntimeError is raised.  ``load()`` only dlopens; compute entry points need a GPU.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libcer_hip.so")
+
+ACT_NONE, ACT_PRELU, ACT_LEAKY, ACT_RELU, ACT_GELU = 0, 1, 2, 3, 4
+
+
+class ConvDesc(Structure):
+    _fields_ = [(n, c_int32) for n in (
+        "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "dil_h", "dil_w", "pad_t", "pad_l",
+        "x_nchw", "res_stride", "Hr", "Wr", "act1", "act2")] + [("slope", c_float), ("split_k", c_int32),
+                                                                ("tile", c_int32)]
+
+
+_P = c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "cer_last_error": (c_char_p, []),
+    "cer_version": (c_int, []),
+    "cer_conv_kpad": (c_int, [c_int, c_int, c_int]),
+    "cer_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
+    "cer_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "cer_pack_conv_weight": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cer_l2norm_rows": (c_int, [_P, _P, c_int, c_int, _P]),
+    "cer_maxpool2x2_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    """Names that include/cer_hip.h declares (used by the CPU-side ABI test)."""
+    return sorted(_SIGNATURES)
+
+
+def load():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m feature_vs_text_compound_emotion_amd.build` "
+            "(there is no CPU fallback for the HIP hot path)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = load().cer_last_error()
+        raise RuntimeError(f"{what} failed with status {rc}: {msg.decode() if msg else ''}")
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    if t is None:
+        return None
+    return c_void_p(t.data_ptr())
+
+
+def current_stream():
+    import torch
+    return c_void_p(torch.cuda.current_stream().cuda_stream)

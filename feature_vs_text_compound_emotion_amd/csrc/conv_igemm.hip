@@ -1,0 +1,460 @@
+// conv_igemm.hip -- implicit-GEMM convolution on the gfx950 fp32 matrix cores.
+//
+// One kernel serves every dense contraction on the hot path (IR-50 convs, the
+// IR-50 head FC, VGGish convs/FCs, TCN causal convs, all Linear layers): the
+// output tile is [BN couts] x [BM pixels], the reduction runs over
+// (kh, kw, cin) in steps of 32, operands are staged global -> registers ->
+// LDS (double buffered, one barrier per step) and consumed by
+// v_mfma_f32_32x32x2_f32 (exact fp32, 64 FLOP/clk/SIMD).
+//
+// Operand roles are chosen so that the accumulator's register index runs over
+// output channels: D[i = cout][j = pixel].  Each lane then owns 4 consecutive
+// couts of one pixel per register quad, which makes the NHWC epilogue
+// (bias / PReLU / residual / mask / store) 16-byte wide.
+//
+// LDS image: [row][k] with k contiguous and a 36-float row pitch.  A lane
+// reads 4 consecutive k of its row with one ds_read_b128 and feeds them to 4
+// successive MFMAs; lane-half h takes k = 8g+4h+j, which is just a fixed
+// permutation of the reduction order shared by both operands.  The 36-float
+// pitch makes ds_read_b128 conflict-free (36*r mod 64 is distinct for the 16
+// rows of a lane group) and ds_write_b128 conflict-free (8 lanes = 128 B).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cer_internal.h"
+
+namespace cer {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int PITCH = 36;  // floats per LDS row
+
+struct ConvArgs {
+    const float *x, *w, *in_scale, *in_shift, *bias, *alpha, *res, *mask;
+    float *y;        // output, or split-K partial slabs [split][M][Cout]
+    int N, H, W, Cin, Ho, Wo, Cout;
+    int KH, KW, stride, dil_h, dil_w, pad_t, pad_l;
+    int x_nchw, res_stride, Hr, Wr, act1, act2;
+    float slope;
+    int Kpad, M, tiles_m, tiles_n, steps, steps_per_split, split_k, cin_steps;
+};
+
+template <int I> struct IdxC { static constexpr int v = I; };
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(IdxC<N - 1>{});
+    }
+}
+
+__device__ __forceinline__ float act_apply(float v, int act, float a, float slope) {
+    switch (act) {
+        case CER_ACT_PRELU: return v >= 0.f ? v : v * a;
+        case CER_ACT_LEAKY: return v >= 0.f ? v : v * slope;
+        case CER_ACT_RELU: return v > 0.f ? v : 0.f;
+        case CER_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        default: return v;
+    }
+}
+
+// Shared epilogue for the fused path and the split-K reducer.
+// v: 4 consecutive couts starting at c for output row m.
+__device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c, float v[4]) {
+    const bool vec = ((p.Cout & 3) == 0);
+    size_t roff = 0;
+    if (p.res) {
+        if (p.res_stride == 1 && p.Hr == p.Ho && p.Wr == p.Wo) {
+            roff = (size_t)m * p.Cout;
+        } else {
+            int hw = p.Ho * p.Wo;
+            int n = m / hw, r = m - n * hw;
+            int ho = r / p.Wo, wo = r - ho * p.Wo;
+            roff = ((size_t)(n * p.Hr + ho * p.res_stride) * p.Wr + wo * p.res_stride) * p.Cout;
+        }
+    }
+    const size_t yoff = (size_t)m * p.Cout + c;
+    if (vec && c + 3 < p.Cout) {
+        float4 b = p.bias ? *reinterpret_cast<const float4 *>(p.bias + c) : make_float4(0, 0, 0, 0);
+        float4 a = (p.act1 == CER_ACT_PRELU) ? *reinterpret_cast<const float4 *>(p.alpha + c) : make_float4(0, 0, 0, 0);
+        float bb[4] = {b.x, b.y, b.z, b.w}, aa[4] = {a.x, a.y, a.z, a.w};
+        float rr[4] = {0, 0, 0, 0}, mm[4] = {1, 1, 1, 1};
+        if (p.res) {
+            float4 r = *reinterpret_cast<const float4 *>(p.res + roff + c);
+            rr[0] = r.x; rr[1] = r.y; rr[2] = r.z; rr[3] = r.w;
+        }
+        if (p.mask) {
+            float4 k = *reinterpret_cast<const float4 *>(p.mask + yoff);
+            mm[0] = k.x; mm[1] = k.y; mm[2] = k.z; mm[3] = k.w;
+        }
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = act_apply(v[e] + bb[e], p.act1, aa[e], p.slope);
+            t = t * mm[e] + rr[e];
+            o[e] = act_apply(t, p.act2, 0.f, p.slope);
+        }
+        *reinterpret_cast<float4 *>(p.y + yoff) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (c + e < p.Cout) {
+                float t = v[e] + (p.bias ? p.bias[c + e] : 0.f);
+                t = act_apply(t, p.act1, p.act1 == CER_ACT_PRELU ? p.alpha[c + e] : 0.f, p.slope);
+                if (p.mask) t *= p.mask[yoff + e];
+                if (p.res) t += p.res[roff + c + e];
+                p.y[yoff + e] = act_apply(t, p.act2, 0.f, p.slope);
+            }
+        }
+    }
+}
+
+template <int BM, int BN, int WP, int WC, bool VEC>
+__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
+    static_assert(WP * WC == 4, "4 waves per block");
+    constexpr int TP = BM / (32 * WP);  // 32-pixel MFMA tiles per wave
+    constexpr int TC = BN / (32 * WC);  // 32-cout MFMA tiles per wave
+    constexpr int XR = BM / 32;         // activation rows staged per thread
+    constexpr int WR = BN / 32;         // weight rows staged per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *Xs = smem;                      // [2][BM][PITCH]
+    float *Ws = smem + 2 * BM * PITCH;     // [2][BN][PITCH]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wp = wave % WP, wc = wave / WP;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    // XCD-aware tile order: blocks b and b+8 share an L2, so give each XCD a
+    // contiguous run of tiles (cout tile fastest: neighbours share activations).
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, c0 = tile_n * BN;
+    const int split = blockIdx.z;
+    const int s_begin = split * p.steps_per_split;
+    const int s_end = min(p.steps, s_begin + p.steps_per_split);
+
+    // ---- staging assignment: thread -> (row srow+32*i, 16-byte chunk) ----
+    const int chunk = tid & 7, srow = tid >> 3;
+    int x_pix[XR], x_hi0[XR], x_wi0[XR];
+    bool x_ok[XR];
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        int m = m0 + srow + 32 * i;
+        x_ok[i] = m < p.M;
+        int mm = x_ok[i] ? m : 0;
+        int hw = p.Ho * p.Wo;
+        int n = mm / hw, r = mm - n * hw;
+        int ho = r / p.Wo, wo = r - ho * p.Wo;
+        x_pix[i] = n;  // image index; pixel offset formed per tap
+        x_hi0[i] = ho * p.stride - p.pad_t;
+        x_wi0[i] = wo * p.stride - p.pad_l;
+    }
+
+    float4 xr[XR], wr[WR];
+    unsigned xvalid = 0;
+    float4 sc = make_float4(1, 1, 1, 1), sh = make_float4(0, 0, 0, 0);
+
+    auto load_step = [&](int s) {
+        if constexpr (VEC) {
+            const int tap = s / p.cin_steps, cc = s - tap * p.cin_steps;
+            const int kh = tap / p.KW, kw = tap - kh * p.KW;
+            const int dh = kh * p.dil_h, dw = kw * p.dil_w;
+            const int cbase = cc * BK + chunk * 4;
+            xvalid = 0;
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                int hi = x_hi0[i] + dh, wi = x_wi0[i] + dw;
+                bool ok = x_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
+                if (ok) {
+                    size_t off = ((size_t)(x_pix[i] * p.H + hi) * p.W + wi) * p.Cin + cbase;
+                    xr[i] = *reinterpret_cast<const float4 *>(p.x + off);
+                    xvalid |= 1u << i;
+                } else {
+                    xr[i] = make_float4(0, 0, 0, 0);
+                }
+            }
+            if (p.in_scale) {
+                sc = *reinterpret_cast<const float4 *>(p.in_scale + cbase);
+                sh = *reinterpret_cast<const float4 *>(p.in_shift + cbase);
+            }
+        } else {
+            // small-Cin gather: k -> (tap, c), element-wise (stem conv, Cin = 1 or 3)
+            const int K = p.KH * p.KW * p.Cin;
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    int k = s * BK + chunk * 4 + j;
+                    float v = 0.f;
+                    if (k < K && x_ok[i]) {
+                        int tap = k / p.Cin, c = k - tap * p.Cin;
+                        int kh = tap / p.KW, kw = tap - kh * p.KW;
+                        int hi = x_hi0[i] + kh * p.dil_h, wi = x_wi0[i] + kw * p.dil_w;
+                        if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
+                            size_t off = p.x_nchw
+                                ? ((size_t)(x_pix[i] * p.Cin + c) * p.H + hi) * p.W + wi
+                                : ((size_t)(x_pix[i] * p.H + hi) * p.W + wi) * p.Cin + c;
+                            v = p.x[off];
+                            if (p.in_scale) v = v * p.in_scale[c] + p.in_shift[c];
+                        }
+                    }
+                    e[j] = v;
+                }
+                xr[i] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < WR; ++i) {
+            int crow = c0 + srow + 32 * i;
+            if (crow < p.Cout)
+                wr[i] = *reinterpret_cast<const float4 *>(p.w + (size_t)crow * p.Kpad + s * BK + chunk * 4);
+            else
+                wr[i] = make_float4(0, 0, 0, 0);
+        }
+    };
+
+    auto store_step = [&](int buf) {
+        float *xs = Xs + buf * BM * PITCH, *ws = Ws + buf * BN * PITCH;
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            float4 v = xr[i];
+            if constexpr (VEC) {
+                if (p.in_scale && ((xvalid >> i) & 1u)) {
+                    v.x = v.x * sc.x + sh.x; v.y = v.y * sc.y + sh.y;
+                    v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
+                }
+            }
+            *reinterpret_cast<float4 *>(xs + (srow + 32 * i) * PITCH + chunk * 4) = v;
+        }
+#pragma unroll
+        for (int i = 0; i < WR; ++i)
+            *reinterpret_cast<float4 *>(ws + (srow + 32 * i) * PITCH + chunk * 4) = wr[i];
+    };
+
+    f32x16 acc[TC][TP];
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    if (s_begin < s_end) {
+        load_step(s_begin);
+        store_step(0);
+    }
+    __syncthreads();
+
+    for (int s = s_begin; s < s_end; ++s) {
+        const int buf = (s - s_begin) & 1;
+        if (s + 1 < s_end) load_step(s + 1);
+        const float *xs = Xs + buf * BM * PITCH + (wp * TP * 32 + l31) * PITCH + half * 4;
+        const float *ws = Ws + buf * BN * PITCH + (wc * TC * 32 + l31) * PITCH + half * 4;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            float4 af[TC], bf[TP];
+#pragma unroll
+            for (int a = 0; a < TC; ++a) af[a] = *reinterpret_cast<const float4 *>(ws + a * 32 * PITCH + g * 8);
+#pragma unroll
+            for (int b = 0; b < TP; ++b) bf[b] = *reinterpret_cast<const float4 *>(xs + b * 32 * PITCH + g * 8);
+#pragma unroll
+            for (int a = 0; a < TC; ++a)
+#pragma unroll
+                for (int b = 0; b < TP; ++b) {
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].x, bf[b].x, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].y, bf[b].y, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].z, bf[b].z, acc[a][b], 0, 0, 0);
+                    acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
+                }
+        }
+        if (s + 1 < s_end) store_step(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: D[i = cout][j = pixel]; reg r -> cout (r&3) + 8*(r>>2) + 4*half ----
+    // (compile-time indices: a runtime-indexed accumulator array would live in scratch)
+    static_for<TP>([&](auto B) {
+        constexpr int b = decltype(B)::v;
+        const int m = m0 + (wp * TP + b) * 32 + l31;
+        static_for<TC>([&](auto A) {
+            constexpr int a = decltype(A)::v;
+            static_for<4>([&](auto Q) {
+                constexpr int q = decltype(Q)::v;
+                const int c = c0 + (wc * TC + a) * 32 + 8 * q + 4 * half;
+                float v[4] = {acc[a][b][4 * q + 0], acc[a][b][4 * q + 1], acc[a][b][4 * q + 2], acc[a][b][4 * q + 3]};
+                if (m < p.M && c < p.Cout) {
+                    if (p.split_k > 1) {
+                        float *dst = p.y + ((size_t)split * p.M + m) * p.Cout + c;
+                        if (((p.Cout & 3) == 0) && c + 3 < p.Cout) {
+                            *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+#pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (c + e < p.Cout) dst[e] = v[e];
+                        }
+                    } else {
+                        epilogue_store4(p, m, c, v);
+                    }
+                }
+            });
+        });
+    });
+}
+
+// Sum split-K slabs and apply the fused epilogue.  One thread per 4 couts.
+__global__ void splitk_reduce_kernel(ConvArgs p, const float *partial) {
+    const int c4 = (p.Cout + 3) >> 2;
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (size_t)p.M * c4) return;
+    int m = (int)(idx / c4), c = (int)(idx - (size_t)m * c4) * 4;
+    float v[4] = {0, 0, 0, 0};
+    const bool vec = ((p.Cout & 3) == 0);
+    for (int s = 0; s < p.split_k; ++s) {
+        const float *src = partial + ((size_t)s * p.M + m) * p.Cout + c;
+        if (vec) {
+            float4 t = *reinterpret_cast<const float4 *>(src);
+            v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < p.Cout) v[e] += src[e];
+        }
+    }
+    epilogue_store4(p, m, c, v);
+}
+
+// ---------------------------------------------------------------- host side
+struct TileCfg { int bm, bn; };
+
+template <int BM, int BN, int WP, int WC>
+static int launch_cfg(const ConvArgs &a, bool vec, hipStream_t st) {
+    const size_t lds = (size_t)2 * (BM + BN) * PITCH * sizeof(float);
+    dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k), block(256);
+    if (vec) {
+        auto k = conv_igemm_kernel<BM, BN, WP, WC, true>;
+        if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, grid, block, lds, st, a);
+    } else {
+        auto k = conv_igemm_kernel<BM, BN, WP, WC, false>;
+        if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(k, grid, block, lds, st, a);
+    }
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+static int pick_tile(const cer_conv_desc *d, int M) {
+    if (d->tile) return d->tile;
+    // 1: 128x128   2: 128x64   3: 256x64   4: 64x128  5: 64x64
+    if (d->Cout <= 64) return M >= 256 * 256 ? 3 : (M >= 128 * 256 ? 2 : 5);
+    if ((long long)((M + 127) / 128) * ((d->Cout + 127) / 128) >= 256) return 1;
+    if (d->Cout <= 96) return 5;
+    return 4;
+}
+
+static void tile_dims(int tile, int &bm, int &bn) {
+    switch (tile) {
+        case 1: bm = 128; bn = 128; break;
+        case 2: bm = 128; bn = 64; break;
+        case 3: bm = 256; bn = 64; break;
+        case 4: bm = 64; bn = 128; break;
+        default: bm = 64; bn = 64; break;
+    }
+}
+
+}  // namespace cer
+
+using namespace cer;
+
+extern "C" int cer_conv_kpad(int KH, int KW, int Cin) {
+    int K = KH * KW * Cin;
+    return (K + BK - 1) / BK * BK;
+}
+
+static int validate_desc(const cer_conv_desc *d) {
+    if (!d) return cer_set_error(CER_ERR_INVALID_ARG, "conv desc is NULL");
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->Cin <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0 ||
+        d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->dil_h <= 0 || d->dil_w <= 0 || d->split_k < 1)
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv desc: non-positive dimension");
+    if ((long long)d->N * d->Ho * d->Wo >= (1ll << 31) || (long long)d->N * d->H * d->W >= (1ll << 31))
+        return cer_set_error(CER_ERR_UNSUPPORTED, "conv desc: more than 2^31 pixels");
+    if (d->x_nchw && (d->Cin % 32) == 0)
+        return cer_set_error(CER_ERR_UNSUPPORTED, "conv desc: NCHW input only on the small-Cin path");
+    return CER_OK;
+}
+
+extern "C" size_t cer_conv2d_workspace_bytes(const cer_conv_desc *d) {
+    if (!d || d->split_k <= 1) return 0;
+    return (size_t)d->split_k * d->N * d->Ho * d->Wo * d->Cout * sizeof(float);
+}
+
+extern "C" int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const float *w,
+                              const float *in_scale, const float *in_shift, const float *bias,
+                              const float *alpha, const float *residual, const float *mask, float *y,
+                              void *workspace, size_t workspace_bytes, void *stream) {
+    int rc = validate_desc(d);
+    if (rc) return rc;
+    if (!x || !w || !y) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: x, w, y must be non-NULL");
+    if ((in_scale == nullptr) != (in_shift == nullptr))
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: in_scale and in_shift go together");
+    if (d->act1 == CER_ACT_PRELU && !alpha)
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: PReLU needs alpha");
+    if (residual && (d->res_stride <= 0 || d->Hr <= 0 || d->Wr <= 0 ||
+                     (d->Ho - 1) * d->res_stride >= d->Hr || (d->Wo - 1) * d->res_stride >= d->Wr))
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: residual geometry out of range");
+    // the deepest input coordinate any output touches must be reachable (others are zero padding)
+    ConvArgs a{};
+    a.x = x; a.w = w; a.in_scale = in_scale; a.in_shift = in_shift; a.bias = bias; a.alpha = alpha;
+    a.res = residual; a.mask = mask; a.y = y;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
+    a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.dil_h = d->dil_h; a.dil_w = d->dil_w;
+    a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.x_nchw = d->x_nchw;
+    a.res_stride = d->res_stride; a.Hr = d->Hr; a.Wr = d->Wr; a.act1 = d->act1; a.act2 = d->act2;
+    a.slope = d->slope;
+    a.Kpad = cer_conv_kpad(d->KH, d->KW, d->Cin);
+    a.M = d->N * d->Ho * d->Wo;
+    const bool vec = (d->Cin % 32) == 0;
+    a.cin_steps = vec ? d->Cin / 32 : 1;
+    a.steps = a.Kpad / BK;
+    a.split_k = d->split_k > a.steps ? a.steps : d->split_k;
+    a.steps_per_split = (a.steps + a.split_k - 1) / a.split_k;
+    a.split_k = (a.steps + a.steps_per_split - 1) / a.steps_per_split;
+    const int tile = pick_tile(d, a.M);
+    int bm, bn;
+    tile_dims(tile, bm, bn);
+    a.tiles_m = (a.M + bm - 1) / bm;
+    a.tiles_n = (a.Cout + bn - 1) / bn;
+    hipStream_t st = (hipStream_t)stream;
+    ConvArgs fin = a;
+    if (a.split_k > 1) {
+        size_t need = (size_t)a.split_k * a.M * a.Cout * sizeof(float);
+        if (!workspace || workspace_bytes < need)
+            return cer_set_error(CER_ERR_WORKSPACE, "conv2d_fwd: split-K workspace too small");
+        a.y = (float *)workspace;
+    }
+    switch (tile) {
+        case 1: rc = launch_cfg<128, 128, 2, 2>(a, vec, st); break;
+        case 2: rc = launch_cfg<128, 64, 2, 2>(a, vec, st); break;
+        case 3: rc = launch_cfg<256, 64, 4, 1>(a, vec, st); break;
+        case 4: rc = launch_cfg<64, 128, 1, 4>(a, vec, st); break;
+        case 5: rc = launch_cfg<64, 64, 2, 2>(a, vec, st); break;
+        default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: unknown tile id");
+    }
+    if (rc) return rc;
+    if (a.split_k > 1) {
+        fin.split_k = a.split_k;
+        size_t n = (size_t)a.M * ((a.Cout + 3) / 4);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fin,
+                           (const float *)workspace);
+        CER_HIP_CHECK(hipGetLastError());
+    }
+    return CER_OK;
+}

@@ -1,0 +1,145 @@
+"""Parity of the implicit-GEMM conv kernel (through the C-ABI) against torch CPU fp32."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-4  # fp32 MFMA is an exact-fp32 fma chain; only summation order differs from the CPU
+
+
+def _ops():
+    from feature_vs_text_compound_emotion_amd import ops
+    return ops
+
+
+def _ref_conv(x_nchw, w, stride, pad, dil=1):
+    return F.conv2d(x_nchw, w, None, stride, pad, dil)
+
+
+@pytest.mark.parametrize("n,cin,cout,hw,k,stride,tile", [
+    (3, 64, 64, 12, 3, 1, 0),
+    (3, 64, 128, 12, 3, 2, 0),
+    (2, 128, 256, 10, 3, 1, 1),
+    (2, 128, 256, 10, 3, 1, 2),
+    (2, 128, 256, 10, 3, 1, 3),
+    (2, 128, 256, 10, 3, 1, 4),
+    (2, 128, 256, 10, 3, 1, 5),
+    (5, 256, 512, 5, 3, 2, 0),
+    (4, 64, 128, 9, 1, 2, 0),
+    (2, 32, 7, 6, 1, 1, 0),     # Cout not a multiple of 4 (regressor-like)
+    (7, 96, 100, 7, 3, 1, 0),   # ragged M and Cout
+])
+def test_conv_plain(n, cin, cout, hw, k, stride, tile):
+    ops = _ops()
+    g = torch.Generator().manual_seed(n * 1000 + cin + cout + hw + k)
+    x = torch.randn(n, cin, hw, hw, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    pad = k // 2
+    ref = _ref_conv(x, w, stride, pad)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    wp = ops.pack_conv_weight(w.cuda())
+    y = ops.conv2d(xd, wp, k, k, stride=stride, pad=(pad, pad), tile=tile)
+    torch.cuda.synchronize()
+    got = y.cpu().permute(0, 3, 1, 2)
+    assert got.shape == ref.shape
+    assert (got - ref).abs().max().item() < TOL
+
+
+def test_conv_small_cin_nchw_stem():
+    ops = _ops()
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 3, 20, 20, generator=g)
+    w = torch.randn(64, 3, 3, 3, generator=g) / 27 ** 0.5
+    ref = _ref_conv(x, w, 1, 1)
+    wp = ops.pack_conv_weight(w.cuda())
+    y = ops.conv2d(x.cuda(), wp, 3, 3, pad=(1, 1), x_nchw=True)
+    assert (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < TOL
+    y2 = ops.conv2d(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, 3, 3, pad=(1, 1))
+    assert (y2.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < TOL
+
+
+def test_conv_fused_prologue_epilogue():
+    """in-affine on in-bounds pixels only, bias, PReLU, strided residual, second activation."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(11)
+    n, cin, cout, hw = 3, 64, 128, 10
+    x = torch.randn(n, cin, hw, hw, generator=g)
+    w = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    sc = torch.rand(cin, generator=g) + 0.5
+    sh = torch.randn(cin, generator=g) * 0.3
+    bias = torch.randn(cout, generator=g)
+    alpha = torch.rand(cout, generator=g) * 0.3 + 0.1
+    res = torch.randn(n, cout, hw, hw, generator=g)
+    xin = x * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    r = _ref_conv(xin, w, 2, 1) + bias.view(1, -1, 1, 1)
+    r = torch.where(r >= 0, r, r * alpha.view(1, -1, 1, 1))
+    r = r + res[:, :, ::2, ::2]
+    ref = F.leaky_relu(r, 0.01)
+    y = ops.conv2d(x.permute(0, 2, 3, 1).contiguous().cuda(), ops.pack_conv_weight(w.cuda()), 3, 3, stride=2,
+                   pad=(1, 1), in_scale=sc.cuda(), in_shift=sh.cuda(), bias=bias.cuda(), alpha=alpha.cuda(),
+                   residual=res.permute(0, 2, 3, 1).contiguous().cuda(), res_stride=2, act1=ops.ACT_PRELU,
+                   act2=ops.ACT_LEAKY)
+    assert (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < TOL
+
+
+def test_conv_bn_fold_scale():
+    ops = _ops()
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(2, 64, 8, 8, generator=g)
+    w = torch.randn(64, 64, 3, 3, generator=g) / 24.0
+    s = torch.rand(64, generator=g) + 0.5
+    ref = _ref_conv(x, w, 1, 1) * s.view(1, -1, 1, 1)
+    wp = ops.pack_conv_weight(w.cuda(), out_scale=s.cuda())
+    y = ops.conv2d(x.permute(0, 2, 3, 1).contiguous().cuda(), wp, 3, 3, pad=(1, 1))
+    assert (y.cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < TOL
+
+
+@pytest.mark.parametrize("split_k", [2, 5, 16])
+def test_linear_split_k(split_k):
+    ops = _ops()
+    g = torch.Generator().manual_seed(13)
+    m, k, cout = 70, 1280, 512
+    x = torch.randn(m, k, generator=g)
+    w = torch.randn(cout, k, generator=g) / k ** 0.5
+    b = torch.randn(cout, generator=g)
+    ref = F.relu(F.linear(x, w, b))
+    y = ops.linear(x.cuda(), w.cuda().contiguous(), bias=b.cuda(), act=ops.ACT_RELU, split_k=split_k)
+    assert (y.cpu() - ref).abs().max().item() < TOL
+
+
+def test_causal_dilated_conv1d_as_conv2d():
+    """TCN conv: [B,L,C] viewed as an [B,L,1,C] image, KHx1 kernel, dilation d, left pad (k-1)d."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(14)
+    b, l, cin, cout, k, d = 3, 32, 128, 64, 5, 4
+    x = torch.randn(b, cin, l, generator=g)
+    w = torch.randn(cout, cin, k, generator=g) / (cin * k) ** 0.5
+    bias = torch.randn(cout, generator=g)
+    ref = F.conv1d(F.pad(x, ((k - 1) * d, 0)), w, bias, dilation=d)
+    xd = x.transpose(1, 2).contiguous().cuda().view(b, l, 1, cin)
+    wp = ops.pack_conv_weight(w.cuda().view(cout, cin, k, 1))
+    y = ops.conv2d(xd, wp, k, 1, dil=(d, 1), pad=((k - 1) * d, 0), out_hw=(l, 1), bias=bias.cuda())
+    got = y.view(b, l, cout).cpu().transpose(1, 2)
+    assert (got - ref).abs().max().item() < TOL
+
+
+def test_l2norm_and_maxpool():
+    ops = _ops()
+    g = torch.Generator().manual_seed(15)
+    x = torch.randn(37, 512, generator=g)
+    assert (ops.l2norm_rows(x.cuda()).cpu() - x / x.norm(dim=1, keepdim=True)).abs().max().item() < 1e-6
+    im = torch.randn(3, 64, 12, 8, generator=g)
+    ref = F.max_pool2d(im, 2, 2)
+    got = ops.maxpool2x2_nhwc(im.permute(0, 2, 3, 1).contiguous().cuda()).cpu().permute(0, 3, 1, 2)
+    assert torch.equal(got, ref)
+
+
+def test_bad_arguments_raise():
+    ops = _ops()
+    x = torch.zeros(1, 4, 4, 64, device="cuda")
+    w = torch.zeros(64, 576, device="cuda")
+    with pytest.raises(RuntimeError):
+        ops.conv2d(x, w, 3, 3, pad=(1, 1), act1=ops.ACT_PRELU)  # PReLU without alpha
+    with pytest.raises(ValueError):
+        ops.conv2d(x.cpu(), w, 3, 3)

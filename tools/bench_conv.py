@@ -1,0 +1,59 @@
+"""Per-shape throughput of the implicit-GEMM conv kernel (algorithmic FLOPs / HIP-event time)."""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from feature_vs_text_compound_emotion_amd import ops  # noqa: E402
+
+# (name, Cin, Cout, H, k, stride) for a 40x40 IR-50; H scales with --hw/40
+SHAPES = [
+    ("s1 64->64", 64, 64, 40, 3, 1),
+    ("s2 64->128", 64, 128, 40, 3, 1),
+    ("s2 128->128 s2", 128, 128, 40, 3, 2),
+    ("s2 128->128", 128, 128, 20, 3, 1),
+    ("s3 128->256", 128, 256, 20, 3, 1),
+    ("s3 256->256 s2", 256, 256, 20, 3, 2),
+    ("s3 256->256", 256, 256, 10, 3, 1),
+    ("s4 256->512", 256, 512, 10, 3, 1),
+    ("s4 512->512 s2", 512, 512, 10, 3, 2),
+    ("s4 512->512", 512, 512, 5, 3, 1),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=1024)
+    ap.add_argument("--hw", type=int, default=40)
+    ap.add_argument("--tiles", default="0")
+    ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--only", default="")
+    a = ap.parse_args()
+    scale = a.hw / 40
+    for name, cin, cout, h, k, stride in SHAPES:
+        if a.only and a.only not in name:
+            continue
+        h = int(h * scale)
+        x = torch.randn(a.frames, h, h, cin, device="cuda")
+        w = torch.randn(cout, ops.conv_kpad(k, k, cin), device="cuda") * 0.02
+        ho = (h + 2 * (k // 2) - k) // stride + 1
+        flops = 2.0 * a.frames * ho * ho * cout * cin * k * k
+        for tile in [int(t) for t in a.tiles.split(",")]:
+            y = torch.empty(a.frames, ho, ho, cout, device="cuda")
+            for _ in range(2):
+                ops.conv2d(x, w, k, k, stride=stride, pad=(k // 2, k // 2), tile=tile, out=y)
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                ops.conv2d(x, w, k, k, stride=stride, pad=(k // 2, k // 2), tile=tile, out=y)
+            e1.record()
+            torch.cuda.synchronize()
+            ms = e0.elapsed_time(e1) / a.iters
+            print(f"{name:18s} H={h:3d} tile={tile} {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s", flush=True)
+
+
+if __name__ == "__main__":
+    main()
