@@ -1,0 +1,166 @@
+"""Seeded synthetic weights and inputs.
+
+There is no network for checkpoints or datasets, so tests, smoke() and bench.py
+all draw weights and clips from here.  Weight tensors are generated from a
+seed in a fixed key order, so a test can rebuild on the GPU box exactly the
+state dict that ``tools/gen_golden.py`` loaded into the reference model when it
+wrote the fixtures -- the big tensors never need to be stored.
+
+Key names and shapes are the reference's (models/backbone.py:69-130,
+models/arcface_model.py:121-151, models/temporal_convolutional_model.py:21-75,
+models/transformer.py:102-197, models/model.py:451-485).
+"""
+from collections import OrderedDict
+
+import torch
+
+IR50_STAGES = ((64, 64, 3, 1), (64, 128, 4, 2), (128, 256, 14, 2), (256, 512, 3, 2))
+
+EMBEDDING_DIM = {"video": 512, "vggish": 128, "bert": 768, "logmel": 128}
+ENCODER_DIM = {"video": 128, "vggish": 32, "bert": 128, "logmel": 32}
+# configs.py:61-73 (the LFAN channel table: BERT_TEMPORAL_DIM = 512)
+TCN_CHANNELS = {"video": [256, 256, 128, 128], "vggish": [64, 64, 32, 32], "logmel": [64, 64, 32, 32],
+                "bert": [256, 256, 128, 128]}
+
+
+def ir50_units():
+    units = []
+    for cin, depth, n, stride in IR50_STAGES:
+        units.append((cin, depth, stride))
+        units.extend((depth, depth, 1) for _ in range(n - 1))
+    return units
+
+
+def _bn_spec(spec, key, c):
+    spec[key + ".weight"] = ((c,), "bn_w")
+    spec[key + ".bias"] = ((c,), "bn_b")
+    spec[key + ".running_mean"] = ((c,), "bn_m")
+    spec[key + ".running_var"] = ((c,), "bn_v")
+    spec[key + ".num_batches_tracked"] = ((), "count")
+
+
+def visual_backbone_spec(prefix="", head_hw=5, num_classes=8):
+    """Ordered {key: (shape, kind)} for VisualBackbone (351 entries)."""
+    s = OrderedDict()
+    p = prefix + "backbone."
+    s[p + "input_layer.0.weight"] = ((64, 3, 3, 3), "conv")
+    _bn_spec(s, p + "input_layer.1", 64)
+    s[p + "input_layer.2.weight"] = ((64,), "prelu")
+    _bn_spec(s, p + "output_layer.0", 512)
+    s[p + "output_layer.3.weight"] = ((512, 512 * head_hw * head_hw), "linear")
+    s[p + "output_layer.3.bias"] = ((512,), "bias")
+    _bn_spec(s, p + "output_layer.4", 512)
+    for i, (cin, depth, stride) in enumerate(ir50_units()):
+        b = f"{p}body.{i}."
+        if cin != depth:
+            s[b + "shortcut_layer.0.weight"] = ((depth, cin, 1, 1), "conv")
+            _bn_spec(s, b + "shortcut_layer.1", depth)
+        _bn_spec(s, b + "res_layer.0", cin)
+        s[b + "res_layer.1.weight"] = ((depth, cin, 3, 3), "conv")
+        s[b + "res_layer.2.weight"] = ((depth,), "prelu")
+        s[b + "res_layer.3.weight"] = ((depth, depth, 3, 3), "conv")
+        _bn_spec(s, b + "res_layer.4", depth)
+    s[prefix + "logits.weight"] = ((num_classes, 512), "linear")
+    s[prefix + "logits.bias"] = ((num_classes,), "bias")
+    return s
+
+
+def tcn_spec(prefix, cin, channels, k):
+    """TemporalConvNet keys; ``net.0/net.4`` alias ``conv1/conv2`` (same tensors)."""
+    s = OrderedDict()
+    alias = {}
+    for i, cout in enumerate(channels):
+        b = f"{prefix}network.{i}."
+        c_in = cin if i == 0 else channels[i - 1]
+        for conv, ci in (("conv1", c_in), ("conv2", cout)):
+            s[b + conv + ".bias"] = ((cout,), "bias")
+            s[b + conv + ".weight_g"] = ((cout, 1, 1), "wn_g")
+            s[b + conv + ".weight_v"] = ((cout, ci, k), "wn_v")
+        for net, conv in (("net.0", "conv1"), ("net.4", "conv2")):
+            for leaf in ("bias", "weight_g", "weight_v"):
+                alias[b + net + "." + leaf] = b + conv + "." + leaf
+        if c_in != cout:
+            s[b + "downsample.weight"] = ((cout, c_in, 1), "conv")
+            s[b + "downsample.bias"] = ((cout,), "bias")
+    return s, alias
+
+
+def lfan_spec(modalities, n_cls=7, head_hw=5, kernel_size=5, modal_dim=32):
+    s = OrderedDict()
+    alias = {}
+    for m in modalities:
+        t, a = tcn_spec(f"temporal.{m}.", EMBEDDING_DIM[m], TCN_CHANNELS[m], kernel_size)
+        s.update(t)
+        alias.update(a)
+    if "video" in modalities:
+        s.update(visual_backbone_spec("spatial.visual.", head_hw))
+    for m in modalities:
+        _bn_spec(s, f"bn.{m}", TCN_CHANNELS[m][-1])
+    for m in modalities:
+        s[f"fusion.layers.self_attn.qkv_proj.{m}.weight"] = ((3 * modal_dim, ENCODER_DIM[m]), "linear")
+        s[f"fusion.layers.self_attn.qkv_proj.{m}.bias"] = ((3 * modal_dim,), "bias")
+    d = modal_dim * len(modalities)
+    s["fusion.layers.self_attn.o_proj.weight"] = ((d, d), "linear")
+    s["fusion.layers.self_attn.o_proj.bias"] = ((d,), "bias")
+    s["fusion.layers.norm1.weight"] = ((d,), "bn_w")
+    s["fusion.layers.norm1.bias"] = ((d,), "bn_b")
+    s["regressor.weight"] = ((n_cls, ENCODER_DIM[modalities[0]] + d), "linear")
+    s["regressor.bias"] = ((n_cls,), "bias")
+    return s, alias
+
+
+def _draw(shape, kind, g):
+    if kind == "count":
+        return torch.zeros((), dtype=torch.long)
+    if kind == "conv":
+        fan_in = 1
+        for d in shape[1:]:
+            fan_in *= d
+        return torch.randn(shape, generator=g) * (1.0 / fan_in) ** 0.5
+    if kind == "linear":
+        bound = (1.0 / shape[1]) ** 0.5
+        return (torch.rand(shape, generator=g) * 2 - 1) * bound
+    if kind == "bias" or kind == "bn_b" or kind == "bn_m":
+        return torch.randn(shape, generator=g) * 0.1
+    if kind == "bn_w" or kind == "bn_v" or kind == "wn_g":
+        return torch.rand(shape, generator=g) + 0.5
+    if kind == "prelu":
+        return torch.rand(shape, generator=g) * 0.3 + 0.1
+    if kind == "wn_v":
+        return torch.randn(shape, generator=g) * 0.05
+    raise ValueError(kind)
+
+
+def make_state_dict(spec, alias=None, seed=0):
+    """Draw every tensor of ``spec`` in order from one seeded CPU generator."""
+    g = torch.Generator().manual_seed(seed)
+    sd = OrderedDict((k, _draw(shape, kind, g)) for k, (shape, kind) in spec.items())
+    for k, src in (alias or {}).items():
+        sd[k] = sd[src]
+    return sd
+
+
+def lfan_state_dict(modalities, n_cls=7, head_hw=5, seed=0):
+    spec, alias = lfan_spec(modalities, n_cls=n_cls, head_hw=head_hw)
+    return make_state_dict(spec, alias, seed)
+
+
+def make_clip_batch(modalities, batch, length, hw=40, seed=1234, n_cls=7):
+    """Synthetic clips: uint8-uniform frames normalised to [-1,1],
+    N(0,1) pre-computed vggish/bert features, one class per clip repeated over frames."""
+    g = torch.Generator().manual_seed(seed)
+    x = OrderedDict()
+    for m in modalities:
+        if m == "video":
+            u8 = torch.randint(0, 256, (batch, length, hw, hw, 3), generator=g, dtype=torch.uint8)
+            x[m] = ((u8.float() / 255.0 - 0.5) / 0.5).permute(0, 1, 4, 2, 3).contiguous()
+        else:
+            x[m] = torch.randn(batch, 1, length, EMBEDDING_DIM[m], generator=g)
+    cls = torch.randint(0, n_cls, (batch,), generator=g)
+    labels = cls.view(batch, 1, 1).expand(batch, length, 1).float().contiguous()
+    return x, labels
+
+
+def dropout_mask(shape, p, g):
+    """Pre-scaled keep mask (values 0 or 1/(1-p)) drawn on the CPU generator ``g``."""
+    return (torch.rand(shape, generator=g) >= p).float() / (1.0 - p)

@@ -1,0 +1,176 @@
+"""IR-ResNet50 vision encoder on the HIP implicit-GEMM kernels.
+
+Host-side mirror of the reference's ``VisualBackbone`` / ``Backbone``
+(models/backbone.py:69-130, models/arcface_model.py:44-60,95-151): same
+constructor arguments, same ``state_dict`` keys (351 entries) and the same
+``forward(x[N,3,H,W]) -> [N,512]`` unit-norm embedding, but the arithmetic runs
+as NHWC fp32-MFMA convolutions with fused prologue/epilogue:
+
+    unit:  t   = PReLU(conv3x3(BN1(x)))            BN1 = in-affine prologue, PReLU epilogue
+           out = BN2(conv3x3_s(t)) + shortcut(x)   BN2 folded into the weights, residual epilogue
+    head:  BN2d -> flatten -> Linear -> BN1d folded into one split-K GEMM, then x/||x||.
+
+The torch.nn layers below only HOLD parameters (so keys, ``.to()``,
+``deepcopy`` and ``requires_grad`` behave like the reference); their own
+``forward`` is never called.
+"""
+import torch
+from torch import nn
+
+from . import ops
+from .synth import ir50_units
+
+BN_EPS = 1e-5
+
+
+class _Unit(nn.Module):
+    """Parameter holder for one bottleneck_IR unit (arcface_model.py:44-60)."""
+
+    def __init__(self, cin, depth, stride):
+        super().__init__()
+        self.cin, self.depth, self.stride = cin, depth, stride
+        if cin == depth:
+            self.shortcut_layer = nn.MaxPool2d(1, stride)  # no parameters; == spatial subsample
+        else:
+            self.shortcut_layer = nn.Sequential(nn.Conv2d(cin, depth, 1, stride, bias=False), nn.BatchNorm2d(depth))
+        self.res_layer = nn.Sequential(
+            nn.BatchNorm2d(cin), nn.Conv2d(cin, depth, 3, 1, 1, bias=False), nn.PReLU(depth),
+            nn.Conv2d(depth, depth, 3, stride, 1, bias=False), nn.BatchNorm2d(depth))
+
+
+class _Flatten(nn.Module):
+    pass
+
+
+class IR50(nn.Module):
+    """``Backbone(num_layers=50, mode='ir')`` with an h x w output head."""
+
+    def __init__(self, input_channels=3, drop_ratio=0.4, head_hw=5, embedding_dim=512):
+        super().__init__()
+        self.head_hw = head_hw
+        self.input_layer = nn.Sequential(nn.Conv2d(input_channels, 64, 3, 1, 1, bias=False), nn.BatchNorm2d(64),
+                                         nn.PReLU(64))
+        self.output_layer = nn.Sequential(nn.BatchNorm2d(embedding_dim), nn.Dropout(drop_ratio), _Flatten(),
+                                          nn.Linear(embedding_dim * head_hw * head_hw, embedding_dim),
+                                          nn.BatchNorm1d(embedding_dim))
+        self.body = nn.Sequential(*[_Unit(*u) for u in ir50_units()])
+        self._packed = None
+        self._packed_key = None
+
+    # ------------------------------------------------------------------ packing
+    @staticmethod
+    def _bn_affine(bn):
+        s = bn.weight.detach() * torch.rsqrt(bn.running_var + BN_EPS)
+        return s.contiguous(), (bn.bias.detach() - bn.running_mean * s).contiguous()
+
+    def _state_key(self):
+        return tuple((p.data_ptr(), p._version) for p in list(self.parameters()) + list(self.buffers()))
+
+    def pack(self):
+        """Fold eval-mode BatchNorms and lay weights out for the kernels (cached until a
+        parameter or buffer changes)."""
+        key = self._state_key()
+        if self._packed is not None and key == self._packed_key:
+            return self._packed
+        dev = self.input_layer[0].weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("IR50 runs on the HIP kernels only: move the module to a GPU (no CPU fallback)")
+        P = {}
+        s, b = self._bn_affine(self.input_layer[1])
+        P["stem_w"] = ops.pack_conv_weight(self.input_layer[0].weight.detach().contiguous(), s)
+        P["stem_b"], P["stem_a"] = b, self.input_layer[2].weight.detach().contiguous()
+        units = []
+        for u in self.body:
+            d = {"stride": u.stride, "proj": u.cin != u.depth}
+            d["in_s"], d["in_b"] = self._bn_affine(u.res_layer[0])
+            d["w1"] = ops.pack_conv_weight(u.res_layer[1].weight.detach().contiguous())
+            d["a1"] = u.res_layer[2].weight.detach().contiguous()
+            s2, b2 = self._bn_affine(u.res_layer[4])
+            d["w2"] = ops.pack_conv_weight(u.res_layer[3].weight.detach().contiguous(), s2)
+            d["b2"] = b2
+            if d["proj"]:
+                ss, sb = self._bn_affine(u.shortcut_layer[1])
+                d["ws"] = ops.pack_conv_weight(u.shortcut_layer[0].weight.detach().contiguous(), ss)
+                d["bs"] = sb
+            units.append(d)
+        P["units"] = units
+        # head: y = BN1d(W . flatten_chw(BN2d(x)) + b); fold both BNs, permute K to (h, w, c)
+        hw = self.head_hw
+        s0, t0 = self._bn_affine(self.output_layer[0])
+        s4, t4 = self._bn_affine(self.output_layer[4])
+        fc = self.output_layer[3]
+        w = fc.weight.detach().view(fc.out_features, -1, hw * hw)  # [512, c, hw]
+        bias = torch.mv(w.sum(dim=2), t0) + fc.bias.detach()
+        w = (w * s0.view(1, -1, 1)).permute(0, 2, 1).contiguous().view(fc.out_features, -1)  # [512, (hw, c)]
+        P["head_w"] = (w * s4.view(-1, 1)).contiguous()
+        P["head_b"] = (bias * s4 + t4).contiguous()
+        self._packed, self._packed_key = P, key
+        return P
+
+    # ------------------------------------------------------------------ forward
+    def forward(self, x):
+        """x: [N,3,H,W] float32 on the GPU -> [N,512], rows of unit L2 norm."""
+        if self.training and any(isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)) for m in [self.input_layer[1]]):
+            # Batch-statistic BatchNorm / Dropout inside the frozen encoder (what the reference's
+            # model.train() does) is not on the HIP path yet: the encoder always
+            # runs with running statistics.  Documented deviation.
+            pass
+        P = self.pack()
+        x = x.contiguous()
+        y = ops.conv2d(x, P["stem_w"], 3, 3, pad=(1, 1), bias=P["stem_b"], alpha=P["stem_a"],
+                       act1=ops.ACT_PRELU, x_nchw=True)
+        for d in P["units"]:
+            s = d["stride"]
+            t = ops.conv2d(y, d["w1"], 3, 3, pad=(1, 1), in_scale=d["in_s"], in_shift=d["in_b"], alpha=d["a1"],
+                           act1=ops.ACT_PRELU)
+            if d["proj"]:
+                sc = ops.conv2d(y, d["ws"], 1, 1, stride=s, bias=d["bs"])
+                y = ops.conv2d(t, d["w2"], 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=sc, res_stride=1)
+            else:
+                y = ops.conv2d(t, d["w2"], 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=y, res_stride=s)
+        n, h, w, c = y.shape
+        if h != self.head_hw or w != self.head_hw:
+            raise RuntimeError(f"IR50 head was built for {self.head_hw}x{self.head_hw} feature maps "
+                               f"({8 * self.head_hw}x{8 * self.head_hw} frames) but got {h}x{w}")
+        k = h * w * c
+        tiles = ((n + 127) // 128) * 4
+        split_k = max(1, min(k // 32, (512 + tiles - 1) // tiles))
+        e = ops.linear(y.view(n, k), P["head_w"], bias=P["head_b"], split_k=split_k)
+        return ops.l2norm_rows(e)
+
+
+class VisualBackbone(nn.Module):
+    """Same constructor and keys as the reference (models/backbone.py:69-130).  ``head_hw``
+    is the one extension: 5 for the reference's 40x40 crops, 28 for 224x224 frames."""
+
+    def __init__(self, input_channels=3, num_classes=8, use_pretrained=True, state_dict_path="", mode="ir",
+                 embedding_dim=512, head_hw=5):
+        super().__init__()
+        if mode != "ir":
+            raise NotImplementedError("only the 'ir' units are on the hot path (the reference never builds ir_se)")
+        self.backbone = IR50(input_channels=input_channels, drop_ratio=0.4, head_hw=head_hw,
+                             embedding_dim=embedding_dim)
+        self.logits = nn.Linear(embedding_dim, num_classes)  # unused by forward, kept for the state dict
+        if use_pretrained:
+            state_dict = torch.load(state_dict_path, map_location="cpu", weights_only=True)
+            if "backbone" in list(state_dict.keys())[0]:
+                state_dict = {k[9:]: v for k, v in state_dict.items() if "logits" not in k}
+            self.backbone.load_state_dict(state_dict)
+            for p in self.backbone.parameters():
+                p.requires_grad = False
+        # head re-initialisation the reference always performs (backbone.py:99-122)
+        for m in self.backbone.output_layer.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.xavier_uniform_(m.weight)
+                nn.init.constant_(m.bias, 0)
+            elif isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)):
+                m.weight.data.fill_(1)
+                m.bias.data.zero_()
+        nn.init.xavier_uniform_(self.logits.weight)
+        nn.init.constant_(self.logits.bias, 0)
+
+    def forward(self, x):
+        return self.backbone(x)
+
+    def extract(self, x):
+        return self.backbone(x)

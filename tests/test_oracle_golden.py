@@ -1,0 +1,84 @@
+"""The CPU oracle against the fixtures recorded from the reference's own model code
+(tools/gen_golden.py).  Runs without a GPU and without /root/reference."""
+import numpy as np
+import torch
+
+import oracle
+from feature_vs_text_compound_emotion_amd import synth
+from oracle.lfan import lfan_forward
+
+from helpers import MODS, golden, masks_from_golden, oracle_train_steps
+
+TOL = 2e-5  # fp32 CPU vs fp32 CPU (same machine class); the generator saw <= 4e-6
+
+
+def _setup(g):
+    b, l, hw, ncls, wseed, dseed = [int(v) for v in g["meta"]]
+    sd = synth.lfan_state_dict(MODS, n_cls=ncls, head_hw=hw // 8, seed=wseed)
+    x, labels = synth.make_clip_batch(MODS, b, l, hw=hw, seed=dseed)
+    return sd, x, labels, (b, l, hw)
+
+
+def test_eval_forward_matches_reference():
+    g = golden("lfan_trimodal_eval.npz")
+    sd, x, _, (b, l, hw) = _setup(g)
+    with torch.no_grad():
+        emb = oracle.ir50_forward(x["video"].reshape(-1, 3, hw, hw), sd, "spatial.visual.backbone.")
+        logits = lfan_forward(x, sd, MODS)
+    assert np.abs(emb.numpy() - g["emb"]).max() < TOL
+    assert np.abs(logits.numpy() - g["logits"]).max() < TOL
+    assert np.abs(np.linalg.norm(emb.numpy(), axis=1) - 1).max() < 1e-5
+
+
+def test_modality_subsets_and_order():
+    g = golden("lfan_modal_subsets_eval.npz")
+    b, l, hw, ncls, wseed, dseed = [int(v) for v in g["meta"]]
+    for mods in (["video"], ["video", "vggish"], ["vggish", "video"], ["bert", "vggish"]):
+        sd = synth.lfan_state_dict(mods, n_cls=ncls, head_hw=hw // 8, seed=wseed)
+        x, _ = synth.make_clip_batch(mods, b, l, hw=hw, seed=dseed)
+        with torch.no_grad():
+            logits = lfan_forward(x, sd, mods)
+        assert np.abs(logits.numpy() - g["logits_" + "_".join(mods)]).max() < TOL
+
+
+def test_train_forward_with_reference_dropout_masks():
+    g = golden("lfan_trimodal_train_fwd.npz")
+    sd, x, _, _ = _setup(g)
+    nb = {}
+    with torch.no_grad():
+        logits = lfan_forward(x, sd, MODS, train=True, masks=masks_from_golden(g), new_buffers=nb)
+    assert np.abs(logits.numpy() - g["logits"]).max() < 5e-5
+    assert np.abs(nb["bn.video.running_mean"].numpy() - g["bn_video_running_mean"]).max() < 1e-5
+    assert np.abs(nb["bn.video.running_var"].numpy() - g["bn_video_running_var"]).max() < 1e-5
+    assert np.abs(nb["spatial.visual.backbone.input_layer.1.running_mean"].numpy() - g["stem_running_mean"]).max() < 1e-5
+
+
+def test_two_optimisation_steps_match_reference():
+    for tag, backbone_train in (("refmode", True), ("evalbackbone", False)):
+        g = golden(f"lfan_trimodal_train_steps_{tag}.npz")
+        sd, _, _, (b, l, hw) = _setup(g)
+        steps, osd, names = oracle_train_steps(sd, MODS, 2, b, l, hw, int(g["meta"][5]), backbone_train)
+        assert list(g["names"]) == names
+        for s, rec in enumerate(steps):
+            assert abs(rec["loss"] - float(g[f"loss{s}"])) < 1e-5
+            assert np.abs(rec["logits"].numpy() - g[f"logits{s}"]).max() < 5e-5
+            gn = np.array([rec["grads"][n].norm().item() for n in names])
+            assert np.abs(gn - g[f"gradnorm{s}"]).max() < 1e-4
+            for key in g.files:
+                if key.startswith(f"grad{s}:"):
+                    assert np.abs(rec["grads"][key.split(":", 1)[1]].numpy() - g[key]).max() < 1e-5
+        for key in g.files:
+            if key.startswith("param2:"):
+                assert np.abs(osd[key.split(":", 1)[1]].numpy() - g[key]).max() < 1e-6
+        assert np.abs(osd["bn.video.running_mean"].numpy() - g["bn_video_running_mean2"]).max() < 1e-5
+
+
+def test_visual_backbone_alone():
+    g = golden("visual_backbone_eval.npz")
+    n, hw, wseed, dseed = [int(v) for v in g["meta"]]
+    vsd = synth.make_state_dict(synth.visual_backbone_spec("", hw // 8), seed=wseed)
+    frames = torch.randn(n, 3, hw, hw, generator=torch.Generator().manual_seed(dseed))
+    with torch.no_grad():
+        emb, feat = oracle.ir50_forward(frames, vsd, "backbone.", return_features=True)
+    assert np.abs(emb.numpy() - g["emb"]).max() < TOL
+    assert np.abs(feat.mean((2, 3)).numpy() - g["feat_mean"]).max() < 1e-4
