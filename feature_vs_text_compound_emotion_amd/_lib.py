@@ -5,7 +5,7 @@ RuntimeError is raised.  ``load()`` only dlopens; compute entry points need a GP
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint64, c_void_p
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libcer_hip.so")
@@ -17,7 +17,8 @@ class ConvDesc(Structure):
     _fields_ = [(n, c_int32) for n in (
         "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "dil_h", "dil_w", "pad_t", "pad_l",
         "x_nchw", "res_stride", "Hr", "Wr", "act1", "act2")] + [("slope", c_float), ("split_k", c_int32),
-                                                                ("tile", c_int32)]
+                                                                ("tile", c_int32), ("x_ld", c_int32),
+                                                                ("y_ld", c_int32)]
 
 
 _P = c_void_p
@@ -27,8 +28,26 @@ _SIGNATURES = {
     "cer_version": (c_int, []),
     "cer_conv_kpad": (c_int, [c_int, c_int, c_int]),
     "cer_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
-    "cer_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
-    "cer_pack_conv_weight": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cer_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "cer_pack_conv_weight": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cer_weight_norm_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "cer_weight_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "cer_conv1d_wgrad": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cer_col_sum_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "cer_col_sum": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
+    "cer_act_mask_bwd": (c_int, [_P, _P, _P, _P, c_size_t, c_float, _P]),
+    "cer_tblock_tail_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_float, _P]),
+    "cer_bn_rows_fwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float,
+                                c_float, _P]),
+    "cer_bn_rows_bwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t,
+                                _P]),
+    "cer_lfan_attn_fwd": (c_int, [POINTER(_P), _P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cer_lfan_attn_bwd": (c_int, [POINTER(_P), _P, _P, POINTER(_P), c_int, c_int, c_int, c_int, _P]),
+    "cer_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_float, _P]),
+    "cer_layernorm_bwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
+    "cer_cross_entropy": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "cer_dropout_mask": (c_int, [_P, c_size_t, c_float, c_uint64, c_uint64, _P]),
+    "cer_copy_cols": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
     "cer_l2norm_rows": (c_int, [_P, _P, c_int, c_int, _P]),
     "cer_maxpool2x2_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
 }

@@ -19,20 +19,23 @@ extern "C" int cer_version(void) { return 100; }
 
 namespace cer {
 
-// OIHW -> [Cout][Kpad], k = (kh*KW + kw)*Cin + c; optional per-cout scale; optional
-// spatial flip (used to build the data-gradient filter of a stride-1 conv).
+// OIHW -> [rows][Kpad].  Forward layout: rows = Cout, k = (kh*KW + kw)*Cin + c, optional
+// per-cout scale (BatchNorm fold).  transpose != 0 builds the DATA-GRADIENT filter of a
+// stride-1 conv instead: rows = Cin, k = (kh*KW + kw)*Cout + o, taps flipped when flip != 0.
 __global__ void pack_conv_weight_kernel(const float *__restrict__ w, const float *__restrict__ scale,
                                         float *__restrict__ out, int Cout, int Cin, int KH, int KW,
-                                        int Kpad, int flip) {
+                                        int Kpad, int flip, int transpose) {
     size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (size_t)Cout * Kpad) return;
-    int o = (int)(idx / Kpad), k = (int)(idx - (size_t)o * Kpad);
+    const int rows = transpose ? Cin : Cout, inner = transpose ? Cout : Cin;
+    if (idx >= (size_t)rows * Kpad) return;
+    int row = (int)(idx / Kpad), k = (int)(idx - (size_t)row * Kpad);
     float v = 0.f;
-    if (k < KH * KW * Cin) {
-        int tap = k / Cin, c = k - tap * Cin;
+    if (k < KH * KW * inner) {
+        int tap = k / inner, c = k - tap * inner;
         int kh = tap / KW, kw = tap - kh * KW;
         if (flip) { kh = KH - 1 - kh; kw = KW - 1 - kw; }
-        v = w[(((size_t)o * Cin + c) * KH + kh) * KW + kw];
+        const int o = transpose ? c : row, i = transpose ? row : c;
+        v = w[(((size_t)o * Cin + i) * KH + kh) * KW + kw];
         if (scale) v *= scale[o];
     }
     out[idx] = v;
@@ -79,13 +82,13 @@ __global__ void maxpool2x2_nhwc_kernel(const float4 *__restrict__ x, float4 *__r
 using namespace cer;
 
 extern "C" int cer_pack_conv_weight(const float *w_oihw, const float *out_scale, float *w_packed, int Cout,
-                                    int Cin, int KH, int KW, int flip, void *stream) {
+                                    int Cin, int KH, int KW, int flip, int transpose, void *stream) {
     if (!w_oihw || !w_packed || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0)
         return cer_set_error(CER_ERR_INVALID_ARG, "pack_conv_weight: bad argument");
-    const int Kpad = cer_conv_kpad(KH, KW, Cin);
-    size_t n = (size_t)Cout * Kpad;
+    const int Kpad = cer_conv_kpad(KH, KW, transpose ? Cout : Cin);
+    size_t n = (size_t)(transpose ? Cin : Cout) * Kpad;
     hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream,
-                       w_oihw, out_scale, w_packed, Cout, Cin, KH, KW, Kpad, flip);
+                       w_oihw, out_scale, w_packed, Cout, Cin, KH, KW, Kpad, flip, transpose);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }

@@ -33,6 +33,8 @@ constexpr int PITCH = 36;  // floats per LDS row
 struct ConvArgs {
     const float *x, *w, *in_scale, *in_shift, *bias, *alpha, *res, *mask;
     float *y;        // output, or split-K partial slabs [split][M][Cout]
+    float *aux;      // optional [M][Cout]: mask*act1(conv+bias), i.e. the value before the residual add
+    int x_ld, y_ld;  // row pitches (floats) of x pixels / y rows
     int N, H, W, Cin, Ho, Wo, Cout;
     int KH, KW, stride, dil_h, dil_w, pad_t, pad_l;
     int x_nchw, res_stride, Hr, Wr, act1, act2;
@@ -73,8 +75,9 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c,
             roff = ((size_t)(n * p.Hr + ho * p.res_stride) * p.Wr + wo * p.res_stride) * p.Cout;
         }
     }
-    const size_t yoff = (size_t)m * p.Cout + c;
-    if (vec && c + 3 < p.Cout) {
+    const size_t yoff = (size_t)m * p.y_ld + c;
+    const size_t doff = (size_t)m * p.Cout + c;  // dense offset (mask, aux)
+    if (vec && ((p.y_ld & 3) == 0) && c + 3 < p.Cout) {
         float4 b = p.bias ? *reinterpret_cast<const float4 *>(p.bias + c) : make_float4(0, 0, 0, 0);
         float4 a = (p.act1 == CER_ACT_PRELU) ? *reinterpret_cast<const float4 *>(p.alpha + c) : make_float4(0, 0, 0, 0);
         float bb[4] = {b.x, b.y, b.z, b.w}, aa[4] = {a.x, a.y, a.z, a.w};
@@ -84,16 +87,17 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c,
             rr[0] = r.x; rr[1] = r.y; rr[2] = r.z; rr[3] = r.w;
         }
         if (p.mask) {
-            float4 k = *reinterpret_cast<const float4 *>(p.mask + yoff);
+            float4 k = *reinterpret_cast<const float4 *>(p.mask + doff);
             mm[0] = k.x; mm[1] = k.y; mm[2] = k.z; mm[3] = k.w;
         }
-        float o[4];
+        float o[4], u[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            float t = act_apply(v[e] + bb[e], p.act1, aa[e], p.slope);
-            t = t * mm[e] + rr[e];
-            o[e] = act_apply(t, p.act2, 0.f, p.slope);
+            float t = act_apply(v[e] + bb[e], p.act1, aa[e], p.slope) * mm[e];
+            u[e] = t;
+            o[e] = act_apply(t + rr[e], p.act2, 0.f, p.slope);
         }
+        if (p.aux) *reinterpret_cast<float4 *>(p.aux + doff) = make_float4(u[0], u[1], u[2], u[3]);
         *reinterpret_cast<float4 *>(p.y + yoff) = make_float4(o[0], o[1], o[2], o[3]);
     } else {
 #pragma unroll
@@ -101,7 +105,8 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c,
             if (c + e < p.Cout) {
                 float t = v[e] + (p.bias ? p.bias[c + e] : 0.f);
                 t = act_apply(t, p.act1, p.act1 == CER_ACT_PRELU ? p.alpha[c + e] : 0.f, p.slope);
-                if (p.mask) t *= p.mask[yoff + e];
+                if (p.mask) t *= p.mask[doff + e];
+                if (p.aux) p.aux[doff + e] = t;
                 if (p.res) t += p.res[roff + c + e];
                 p.y[yoff + e] = act_apply(t, p.act2, 0.f, p.slope);
             }
@@ -173,7 +178,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
                 int hi = x_hi0[i] + dh, wi = x_wi0[i] + dw;
                 bool ok = x_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
                 if (ok) {
-                    size_t off = ((size_t)(x_pix[i] * p.H + hi) * p.W + wi) * p.Cin + cbase;
+                    size_t off = ((size_t)(x_pix[i] * p.H + hi) * p.W + wi) * p.x_ld + cbase;
                     xr[i] = *reinterpret_cast<const float4 *>(p.x + off);
                     xvalid |= 1u << i;
                 } else {
@@ -201,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
                         if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) {
                             size_t off = p.x_nchw
                                 ? ((size_t)(x_pix[i] * p.Cin + c) * p.H + hi) * p.W + wi
-                                : ((size_t)(x_pix[i] * p.H + hi) * p.W + wi) * p.Cin + c;
+                                : ((size_t)(x_pix[i] * p.H + hi) * p.W + wi) * p.x_ld + c;
                             v = p.x[off];
                             if (p.in_scale) v = v * p.in_scale[c] + p.in_shift[c];
                         }
@@ -399,7 +404,7 @@ extern "C" size_t cer_conv2d_workspace_bytes(const cer_conv_desc *d) {
 extern "C" int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const float *w,
                               const float *in_scale, const float *in_shift, const float *bias,
                               const float *alpha, const float *residual, const float *mask, float *y,
-                              void *workspace, size_t workspace_bytes, void *stream) {
+                              float *aux, void *workspace, size_t workspace_bytes, void *stream) {
     int rc = validate_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: x, w, y must be non-NULL");
@@ -413,7 +418,13 @@ extern "C" int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const floa
     // the deepest input coordinate any output touches must be reachable (others are zero padding)
     ConvArgs a{};
     a.x = x; a.w = w; a.in_scale = in_scale; a.in_shift = in_shift; a.bias = bias; a.alpha = alpha;
-    a.res = residual; a.mask = mask; a.y = y;
+    a.res = residual; a.mask = mask; a.y = y; a.aux = aux;
+    a.x_ld = d->x_ld > 0 ? d->x_ld : d->Cin;
+    a.y_ld = d->y_ld > 0 ? d->y_ld : d->Cout;
+    if (a.x_ld < d->Cin || a.y_ld < d->Cout || ((d->Cin % 32) == 0 && (a.x_ld & 3) != 0))
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: x_ld/y_ld smaller than the channel count or x_ld % 4 != 0");
+    if (d->x_nchw && d->x_ld > 0)
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: x_ld is meaningless for NCHW input");
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.dil_h = d->dil_h; a.dil_w = d->dil_w;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.x_nchw = d->x_nchw;

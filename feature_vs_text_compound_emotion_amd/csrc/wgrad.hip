@@ -1,0 +1,126 @@
+// wgrad.hip -- weight gradient of the causal dilated conv1d / linear layers of the
+// trainable tail on the fp32 matrix cores.
+//
+//   dW[co][ci][j] = sum_r dZ[r][co] * X[r - (k-1-j)*dil][ci]      (source row inside the same
+//                                                                 length-L sequence, else 0)
+//
+// This is a "TN" GEMM whose reduction index is the row r, which is the slow axis of both
+// operands.  v_mfma_f32_32x32x2_f32 wants A[i][k] / B[k][j] with lane = (i or j) and the
+// two k of a step in the lane halves, so the natural row-major LDS image [k = row][channel]
+// is read with conflict-free ds_read_b32 (32 consecutive floats per half-wave): no
+// transpose is needed anywhere.
+#include "cer_internal.h"
+
+namespace cer {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+struct WgradArgs {
+    const float *dz, *x;
+    float *dw;
+    int R, L, Cout, Cin, k, dil, dz_ld, x_ld;
+};
+
+constexpr int WG_ROWS = 32;  // reduction rows per step
+constexpr int WG_T = 64;     // output tile edge (couts x cins)
+constexpr int WG_PITCH = 64;
+
+__global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs p) {
+    __shared__ __attribute__((aligned(16))) float As[2][WG_ROWS][WG_PITCH];  // dZ tile  [row][cout]
+    __shared__ __attribute__((aligned(16))) float Bs[2][WG_ROWS][WG_PITCH];  // X tile   [row][cin]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ti = wave & 1, tj = wave >> 1;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int co0 = blockIdx.x * WG_T, ci0 = blockIdx.y * WG_T, tap = blockIdx.z;
+    const int shift = (p.k - 1 - tap) * p.dil;
+
+    // staging: 32 rows x 16 float4 per operand = 512 float4 -> 2 per thread per operand
+    const int srow = tid >> 4, scol = (tid & 15) * 4;
+    float4 ra[2], rb[2];
+    auto load_step = [&](int r0) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = r0 + srow + 16 * i;
+            float4 a = make_float4(0, 0, 0, 0), b = make_float4(0, 0, 0, 0);
+            if (r < p.R) {
+                const int co = co0 + scol, ci = ci0 + scol;
+                const float *ap = p.dz + (size_t)r * p.dz_ld + co;
+                if (co + 3 < p.Cout && ((p.dz_ld & 3) == 0)) {
+                    a = *reinterpret_cast<const float4 *>(ap);
+                } else {
+                    if (co < p.Cout) a.x = ap[0];
+                    if (co + 1 < p.Cout) a.y = ap[1];
+                    if (co + 2 < p.Cout) a.z = ap[2];
+                    if (co + 3 < p.Cout) a.w = ap[3];
+                }
+                const int t = r % p.L;
+                if (t >= shift) {
+                    const float *bp = p.x + (size_t)(r - shift) * p.x_ld + ci;
+                    if (ci + 3 < p.Cin && ((p.x_ld & 3) == 0)) {
+                        b = *reinterpret_cast<const float4 *>(bp);
+                    } else {
+                        if (ci < p.Cin) b.x = bp[0];
+                        if (ci + 1 < p.Cin) b.y = bp[1];
+                        if (ci + 2 < p.Cin) b.z = bp[2];
+                        if (ci + 3 < p.Cin) b.w = bp[3];
+                    }
+                }
+            }
+            ra[i] = a;
+            rb[i] = b;
+        }
+    };
+    auto store_step = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            *reinterpret_cast<float4 *>(&As[buf][srow + 16 * i][scol]) = ra[i];
+            *reinterpret_cast<float4 *>(&Bs[buf][srow + 16 * i][scol]) = rb[i];
+        }
+    };
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    const int steps = (p.R + WG_ROWS - 1) / WG_ROWS;
+    load_step(0);
+    store_step(0);
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < steps) load_step((s + 1) * WG_ROWS);
+#pragma unroll
+        for (int kk = 0; kk < WG_ROWS / 2; ++kk) {
+            const float a = As[buf][2 * kk + half][ti * 32 + l31];
+            const float b = Bs[buf][2 * kk + half][tj * 32 + l31];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        if (s + 1 < steps) store_step(buf ^ 1);
+        __syncthreads();
+    }
+    // D[i = cout][j = cin]: lane -> cin, register r -> cout (r&3) + 8*(r>>2) + 4*half
+    const int ci = ci0 + tj * 32 + l31;
+    if (ci < p.Cin) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + ti * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < p.Cout) p.dw[((size_t)co * p.Cin + ci) * p.k + tap] = acc[r];
+        }
+    }
+}
+
+}  // namespace cer
+
+using namespace cer;
+
+extern "C" int cer_conv1d_wgrad(const float *dz, int dz_ld, const float *x, int x_ld, float *dw, int R, int L,
+                                int Cout, int Cin, int k, int dil, void *stream) {
+    if (!dz || !x || !dw || R <= 0 || L <= 0 || Cout <= 0 || Cin <= 0 || k <= 0 || dil <= 0 || dz_ld < Cout ||
+        x_ld < Cin || (R % L) != 0)
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv1d_wgrad: bad argument (R must be a multiple of L)");
+    WgradArgs a{dz, x, dw, R, L, Cout, Cin, k, dil, dz_ld, x_ld};
+    dim3 grid((Cout + WG_T - 1) / WG_T, (Cin + WG_T - 1) / WG_T, k);
+    hipLaunchKernelGGL(conv1d_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}

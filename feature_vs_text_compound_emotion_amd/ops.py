@@ -10,40 +10,62 @@ import torch
 from . import _lib
 from ._lib import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_PRELU, ACT_RELU, ConvDesc, check, current_stream, ptr  # noqa: F401
 
+LEAKY_SLOPE = 0.01
 
-def _dev_f32(t, name):
+
+def _dev_f32(t, name, contiguous=True):
     if t is None:
         return
-    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+    if not (t.is_cuda and t.dtype == torch.float32 and (t.is_contiguous() or not contiguous)):
         raise ValueError(f"{name}: expected a contiguous float32 tensor on the GPU, got "
                          f"{t.dtype} {t.device} contiguous={t.is_contiguous()}")
+
+
+def _rows(t, name):
+    """Accept a [R,C] tensor that is dense or a column slice of a wider row-major buffer.
+    Returns (rows, cols, pitch)."""
+    if not (t.is_cuda and t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1):
+        raise ValueError(f"{name}: expected a 2-D float32 GPU tensor with unit column stride")
+    return t.shape[0], t.shape[1], (t.stride(0) if t.shape[0] > 1 else max(t.stride(0), t.shape[1]))
+
+
+def _empty(shape, like):
+    return torch.empty(shape, device=like.device, dtype=torch.float32)
 
 
 def conv_kpad(kh, kw, cin):
     return _lib.load().cer_conv_kpad(kh, kw, cin)
 
 
-def pack_conv_weight(w_oihw, out_scale=None, flip=False):
-    """[Cout,Cin,KH,KW] -> [Cout,Kpad] with k = (kh*KW+kw)*Cin + c, BN scale folded."""
+def pack_conv_weight(w_oihw, out_scale=None, flip=False, transpose=False):
+    """[Cout,Cin,KH,KW] -> [Cout,Kpad] with k = (kh*KW+kw)*Cin + c, BN scale folded;
+    ``transpose`` gives the data-gradient filter [Cin, Kpad(KH,KW,Cout)]."""
     _dev_f32(w_oihw, "w_oihw")
     _dev_f32(out_scale, "out_scale")
     cout, cin, kh, kw = w_oihw.shape
-    out = torch.empty((cout, conv_kpad(kh, kw, cin)), device=w_oihw.device, dtype=torch.float32)
+    rows, inner = (cin, cout) if transpose else (cout, cin)
+    out = _empty((rows, conv_kpad(kh, kw, inner)), w_oihw)
     check(_lib.load().cer_pack_conv_weight(ptr(w_oihw), ptr(out_scale), ptr(out), cout, cin, kh, kw,
-                                           1 if flip else 0, current_stream()), "cer_pack_conv_weight")
+                                           1 if flip else 0, 1 if transpose else 0, current_stream()),
+          "cer_pack_conv_weight")
     return out
 
 
 def conv2d(x, w_packed, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, in_scale=None,
            in_shift=None, bias=None, alpha=None, residual=None, res_stride=1, mask=None, act1=ACT_NONE,
-           act2=ACT_NONE, slope=0.01, split_k=1, x_nchw=False, tile=0, out=None):
+           act2=ACT_NONE, slope=LEAKY_SLOPE, split_k=1, x_nchw=False, tile=0, out=None, aux=None, x_ld=0, y_ld=0,
+           x_shape=None):
     """y[N,Ho,Wo,Cout] = act2(mask*act1(conv(affine(x), w)+bias) + residual).  x is NHWC
-    (or NCHW with ``x_nchw`` on the small-Cin path)."""
+    (or NCHW with ``x_nchw`` on the small-Cin path).  ``x_shape`` = (N,H,W,Cin) overrides
+    x.shape when x is a column slice (then ``x_ld`` is its row pitch)."""
     lib = _lib.load()
-    for t, n in ((x, "x"), (w_packed, "w"), (in_scale, "in_scale"), (in_shift, "in_shift"), (bias, "bias"),
-                 (alpha, "alpha"), (residual, "residual"), (mask, "mask")):
+    for t, n in ((w_packed, "w"), (in_scale, "in_scale"), (in_shift, "in_shift"), (bias, "bias"),
+                 (alpha, "alpha"), (residual, "residual"), (mask, "mask"), (aux, "aux")):
         _dev_f32(t, n)
-    if x_nchw:
+    _dev_f32(x, "x", contiguous=(x_ld == 0))
+    if x_shape is not None:
+        n, h, w, cin = x_shape
+    elif x_nchw:
         n, cin, h, w = x.shape
     else:
         n, h, w, cin = x.shape
@@ -60,6 +82,7 @@ def conv2d(x, w_packed, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None
     d.KH, d.KW, d.stride, d.dil_h, d.dil_w, d.pad_t, d.pad_l = kh, kw, stride, dil[0], dil[1], pad[0], pad[1]
     d.x_nchw = 1 if x_nchw else 0
     d.res_stride, d.Hr, d.Wr = res_stride, 0, 0
+    d.x_ld, d.y_ld = x_ld, y_ld
     if residual is not None:
         if residual.shape[0] != n or residual.shape[3] != cout:
             raise ValueError(f"residual shape {tuple(residual.shape)} does not match N={n}, Cout={cout}")
@@ -68,30 +91,37 @@ def conv2d(x, w_packed, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None
                            (alpha, "alpha", cout)):
         if t is not None and t.numel() != length:
             raise ValueError(f"{nme} has {t.numel()} elements, expected {length}")
-    if mask is not None and mask.numel() != n * ho * wo * cout:
-        raise ValueError("mask must have the output's shape")
+    for t, nme in ((mask, "mask"), (aux, "aux")):
+        if t is not None and t.numel() != n * ho * wo * cout:
+            raise ValueError(f"{nme} must have the output's shape")
     d.act1, d.act2, d.slope, d.split_k, d.tile = act1, act2, slope, split_k, tile
     if out is None:
-        out = torch.empty((n, ho, wo, cout), device=x.device, dtype=torch.float32)
+        if y_ld:
+            raise ValueError("y_ld needs an explicit out buffer")
+        out = _empty((n, ho, wo, cout), x)
     else:
-        _dev_f32(out, "out")
-        if out.numel() != n * ho * wo * cout:
-            raise ValueError("out has the wrong size")
+        _dev_f32(out, "out", contiguous=(y_ld == 0))
     ws_bytes = lib.cer_conv2d_workspace_bytes(ctypes.byref(d))
-    ws = torch.empty((ws_bytes // 4,), device=x.device, dtype=torch.float32) if ws_bytes else None
+    ws = _empty((ws_bytes // 4,), x) if ws_bytes else None
     check(lib.cer_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_packed), ptr(in_scale), ptr(in_shift), ptr(bias),
-                             ptr(alpha), ptr(residual), ptr(mask), ptr(out), ptr(ws), ws_bytes,
+                             ptr(alpha), ptr(residual), ptr(mask), ptr(out), ptr(aux), ptr(ws), ws_bytes,
                              current_stream()), "cer_conv2d_fwd")
     return out
 
 
 def linear(x2d, w_packed, bias=None, act=ACT_NONE, split_k=1, residual=None, out=None):
-    """[M,K] @ W[Cout,K]^T as a 1x1 conv on an [M,1,1,K] image."""
-    m, k = x2d.shape
+    """[M,K] @ W[Cout,K]^T as a 1x1 conv on an [M,1,1,K] image.  x2d / out may be column
+    slices of wider row-major buffers."""
+    m, k, x_ld = _rows(x2d, "x2d")
     res = residual.view(m, 1, 1, -1) if residual is not None else None
-    y = conv2d(x2d.view(m, 1, 1, k), w_packed, 1, 1, bias=bias, act1=act, split_k=split_k, residual=res,
-               out=out)
-    return y.view(m, -1)
+    y_ld = 0
+    if out is not None:
+        _, _, y_ld = _rows(out, "out")
+        if y_ld == out.shape[1]:
+            y_ld = 0
+    y = conv2d(x2d, w_packed, 1, 1, bias=bias, act1=act, split_k=split_k, residual=res, out=out,
+               x_ld=(0 if x_ld == k else x_ld), y_ld=y_ld, x_shape=(m, 1, 1, k))
+    return y if out is not None else y.view(m, -1)
 
 
 def l2norm_rows(x):
@@ -105,6 +135,180 @@ def l2norm_rows(x):
 def maxpool2x2_nhwc(x):
     _dev_f32(x, "x")
     n, h, w, c = x.shape
-    y = torch.empty((n, h // 2, w // 2, c), device=x.device, dtype=torch.float32)
+    y = _empty((n, h // 2, w // 2, c), x)
     check(_lib.load().cer_maxpool2x2_nhwc(ptr(x), ptr(y), n, h, w, c, current_stream()), "cer_maxpool2x2_nhwc")
     return y
+
+
+# ------------------------------------------------------------------ trainable tail
+def weight_norm_fwd(v, g):
+    """v [Cout,Cin,k], g [Cout,1,1] -> (w [Cout,Cin,k], norm [Cout])."""
+    _dev_f32(v, "v")
+    _dev_f32(g, "g")
+    rows, e = v.shape[0], v.numel() // v.shape[0]
+    w, norm = torch.empty_like(v), _empty((rows,), v)
+    check(_lib.load().cer_weight_norm_fwd(ptr(v), ptr(g), ptr(w), ptr(norm), rows, e, current_stream()),
+          "cer_weight_norm_fwd")
+    return w, norm
+
+
+def weight_norm_bwd(dw, v, g, norm):
+    for t, n in ((dw, "dw"), (v, "v"), (g, "g"), (norm, "norm")):
+        _dev_f32(t, n)
+    rows, e = v.shape[0], v.numel() // v.shape[0]
+    dv, dg = torch.empty_like(v), torch.empty_like(g)
+    check(_lib.load().cer_weight_norm_bwd(ptr(dw), ptr(v), ptr(g), ptr(norm), ptr(dv), ptr(dg), rows, e,
+                                          current_stream()), "cer_weight_norm_bwd")
+    return dv, dg
+
+
+def conv1d_wgrad(dz, x, seq_len, k, dil):
+    """dW [Cout,Cin,k] from dz [R,Cout] and the layer input x [R,Cin] (both may be column slices)."""
+    r, cout, dz_ld = _rows(dz, "dz")
+    r2, cin, x_ld = _rows(x, "x")
+    if r != r2:
+        raise ValueError("dz and x must have the same number of rows")
+    dw = _empty((cout, cin, k), dz)
+    check(_lib.load().cer_conv1d_wgrad(ptr(dz), dz_ld, ptr(x), x_ld, ptr(dw), r, seq_len, cout, cin, k, dil,
+                                       current_stream()), "cer_conv1d_wgrad")
+    return dw
+
+
+def _col_ws(r, c, like):
+    nbytes = _lib.load().cer_col_sum_workspace_bytes(r, c)
+    return (_empty((nbytes // 4,), like) if nbytes else None), nbytes
+
+
+def col_sum(a):
+    """Column sums of a [R,C] tensor (bias gradients)."""
+    r, c, ld = _rows(a, "a")
+    out = _empty((c,), a)
+    ws, nbytes = _col_ws(r, c, a)
+    check(_lib.load().cer_col_sum(ptr(a), ld, None, 0, None, None, ptr(out), r, c, ptr(ws), nbytes,
+                                  current_stream()), "cer_col_sum")
+    return out
+
+
+def act_mask_bwd(dy, y, mask=None, slope=LEAKY_SLOPE):
+    for t, n in ((dy, "dy"), (y, "y"), (mask, "mask")):
+        _dev_f32(t, n)
+    dz = torch.empty_like(dy)
+    check(_lib.load().cer_act_mask_bwd(ptr(dy), ptr(y), ptr(mask), ptr(dz), dy.numel(), slope, current_stream()),
+          "cer_act_mask_bwd")
+    return dz
+
+
+def tblock_tail_bwd(dout, out, a2, mask2=None, slope=LEAKY_SLOPE):
+    for t, n in ((dout, "dout"), (out, "out"), (a2, "a2"), (mask2, "mask2")):
+        _dev_f32(t, n)
+    du, dz2 = torch.empty_like(dout), torch.empty_like(dout)
+    check(_lib.load().cer_tblock_tail_bwd(ptr(dout), ptr(out), ptr(a2), ptr(mask2), ptr(du), ptr(dz2),
+                                          dout.numel(), slope, current_stream()), "cer_tblock_tail_bwd")
+    return du, dz2
+
+
+def bn_rows_fwd(x, w, b, running_mean, running_var, train, eps=1e-5, momentum=0.1, out=None):
+    """BatchNorm over the rows of x [R,C].  Returns (y, save_mean, save_invstd); the saves are
+    None in eval mode.  Running stats are updated in place when ``train``."""
+    r, c, x_ld = _rows(x, "x")
+    for t, n in ((w, "w"), (b, "b"), (running_mean, "running_mean"), (running_var, "running_var")):
+        _dev_f32(t, n)
+    if out is None:
+        out = _empty((r, c), x)
+    _, _, y_ld = _rows(out, "out")
+    sm = _empty((c,), x) if train else None
+    si = _empty((c,), x) if train else None
+    check(_lib.load().cer_bn_rows_fwd(ptr(x), x_ld, ptr(w), ptr(b), ptr(running_mean), ptr(running_var), ptr(sm),
+                                      ptr(si), ptr(out), y_ld, r, c, 1 if train else 0, eps, momentum,
+                                      current_stream()), "cer_bn_rows_fwd")
+    return out, sm, si
+
+
+def bn_rows_bwd(dy, x, save_mean, save_invstd, w, train=True):
+    r, c, dy_ld = _rows(dy, "dy")
+    _, _, x_ld = _rows(x, "x")
+    dx, dw, db = _empty((r, c), x), _empty((c,), x), _empty((c,), x)
+    ws, nbytes = _col_ws(r, c, x)
+    check(_lib.load().cer_bn_rows_bwd(ptr(dy), dy_ld, ptr(x), x_ld, ptr(save_mean), ptr(save_invstd), ptr(w),
+                                      ptr(dx), ptr(dw), ptr(db), r, c, 1 if train else 0, ptr(ws), nbytes,
+                                      current_stream()), "cer_bn_rows_bwd")
+    return dx, dw, db
+
+
+def _ptr_array(tensors):
+    arr = (ctypes.c_void_p * len(tensors))()
+    for i, t in enumerate(tensors):
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def lfan_attn_fwd(qkv_list, num_heads, head_dim):
+    """qkv_list: per modality [R, H*3*hd] -> (vals [R, H*M*hd], probs [R,H,M,M])."""
+    for t in qkv_list:
+        _dev_f32(t, "qkv")
+    r, m = qkv_list[0].shape[0], len(qkv_list)
+    vals = _empty((r, num_heads * m * head_dim), qkv_list[0])
+    probs = _empty((r, num_heads, m, m), qkv_list[0])
+    check(_lib.load().cer_lfan_attn_fwd(_ptr_array(qkv_list), ptr(vals), ptr(probs), r, num_heads, m, head_dim,
+                                        current_stream()), "cer_lfan_attn_fwd")
+    return vals, probs
+
+
+def lfan_attn_bwd(qkv_list, dvals, probs, num_heads, head_dim):
+    _dev_f32(dvals, "dvals")
+    r, m = qkv_list[0].shape[0], len(qkv_list)
+    dqkv = [torch.empty_like(t) for t in qkv_list]
+    check(_lib.load().cer_lfan_attn_bwd(_ptr_array(qkv_list), ptr(dvals), ptr(probs), _ptr_array(dqkv), r,
+                                        num_heads, m, head_dim, current_stream()), "cer_lfan_attn_bwd")
+    return dqkv
+
+
+def layernorm_fwd(x, gamma, beta, mask=None, eps=1e-5, out=None, save=True):
+    _dev_f32(x, "x")
+    _dev_f32(mask, "mask")
+    r, c = x.shape
+    if out is None:
+        out = _empty((r, c), x)
+    _, _, y_ld = _rows(out, "out")
+    mean = _empty((r,), x) if save else None
+    rstd = _empty((r,), x) if save else None
+    check(_lib.load().cer_layernorm_fwd(ptr(x), ptr(mask), ptr(gamma), ptr(beta), ptr(out), y_ld, ptr(mean),
+                                        ptr(rstd), r, c, eps, current_stream()), "cer_layernorm_fwd")
+    return out, mean, rstd
+
+
+def layernorm_bwd(dy, x, gamma, mean, rstd, mask=None):
+    r, c, dy_ld = _rows(dy, "dy")
+    dx, scratch = _empty((r, c), x), _empty((r, c), x)
+    dg, db = _empty((c,), x), _empty((c,), x)
+    ws, nbytes = _col_ws(r, c, x)
+    check(_lib.load().cer_layernorm_bwd(ptr(dy), dy_ld, ptr(x), ptr(mask), ptr(gamma), ptr(mean), ptr(rstd), ptr(dx),
+                                        ptr(dg), ptr(db), ptr(scratch), r, c, ptr(ws), nbytes, current_stream()),
+          "cer_layernorm_bwd")
+    return dx, dg, db
+
+
+def cross_entropy(logits2d, labels_f32, want_grad=True):
+    """Mean CE over rows; labels are float32 class ids (cast like ``.long()``).  Returns
+    (loss scalar tensor, dlogits or None)."""
+    _dev_f32(logits2d, "logits")
+    _dev_f32(labels_f32, "labels")
+    r, c = logits2d.shape
+    loss = _empty((), logits2d)
+    dl = torch.empty_like(logits2d) if want_grad else None
+    check(_lib.load().cer_cross_entropy(ptr(logits2d), ptr(labels_f32), ptr(loss), ptr(dl), r, c, current_stream()),
+          "cer_cross_entropy")
+    return loss, dl
+
+
+def dropout_mask(shape, p, seed, offset, device):
+    m = torch.empty(shape, device=device, dtype=torch.float32)
+    check(_lib.load().cer_dropout_mask(ptr(m), m.numel(), p, seed, offset, current_stream()), "cer_dropout_mask")
+    return m
+
+
+def copy_cols(x, out):
+    r, c, x_ld = _rows(x, "x")
+    _, _, y_ld = _rows(out, "out")
+    check(_lib.load().cer_copy_cols(ptr(x), x_ld, ptr(out), y_ld, r, c, current_stream()), "cer_copy_cols")
+    return out

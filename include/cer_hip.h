@@ -62,6 +62,8 @@ int cer_version(void);
  *   residual [N,Hr,Wr,Cout] or NULL, sampled at (ho*res_stride, wo*res_stride)
  *            (MaxPool2d(1,stride) shortcut == spatial subsample)
  *   mask     [N,Ho,Wo,Cout] or NULL (pre-scaled dropout mask)
+ *   aux      [N,Ho,Wo,Cout] or NULL: receives mask*act1(conv+bias), the value before
+ *            the residual add (saved for the backward pass of a TemporalBlock)
  *   split_k  >= 1; > 1 needs `workspace` of cer_conv2d_workspace_bytes()
  * ---------------------------------------------------------------------- */
 typedef struct cer_conv_desc {
@@ -74,6 +76,8 @@ typedef struct cer_conv_desc {
     float slope;          /* LeakyReLU slope */
     int32_t split_k;
     int32_t tile;         /* 0 = auto; else forces a tile config (testing / tuning) */
+    int32_t x_ld, y_ld;   /* pitch in floats between pixels of x / rows of y; 0 = dense (Cin / Cout).
+                             Lets a layer read or write a column slice of a wider [rows, ld] buffer. */
 } cer_conv_desc;
 
 int cer_conv_kpad(int KH, int KW, int Cin);
@@ -82,18 +86,88 @@ int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const float *w,
                    const float *in_scale, const float *in_shift,
                    const float *bias, const float *alpha,
                    const float *residual, const float *mask,
-                   float *y, void *workspace, size_t workspace_bytes, void *stream);
+                   float *y, float *aux, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Pack an OIHW (torch) conv weight into [Cout][Kpad] with optional per-output
- * scale (BatchNorm fold).  w_oihw [Cout,Cin,KH,KW]; out_scale [Cout] or NULL. */
+ * scale (BatchNorm fold).  w_oihw [Cout,Cin,KH,KW]; out_scale [Cout] or NULL.
+ * transpose != 0 writes the data-gradient filter instead: [Cin][Kpad'] with
+ * k = tap*Cout + o (taps flipped when flip != 0), so that
+ * dX = cer_conv2d_fwd(dY, packed_T) with the padding mirrored. */
 int cer_pack_conv_weight(const float *w_oihw, const float *out_scale, float *w_packed,
-                         int Cout, int Cin, int KH, int KW, int flip, void *stream);
+                         int Cout, int Cin, int KH, int KW, int flip, int transpose, void *stream);
 
 /* rows x / ||x||_2, no epsilon (reference models/arcface_model.py:17-20). */
 int cer_l2norm_rows(const float *x, float *y, int rows, int cols, void *stream);
 
 /* max-pool 2x2 stride 2 on NHWC (reference models/backbone.py:45-46). */
 int cer_maxpool2x2_nhwc(const float *x, float *y, int N, int H, int W, int C, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Trainable tail (rows = B*L frames, channels-last).  Forward AND backward,
+ * because this is the part of the model the reference actually trains
+ * (models/model.py:432-433 freezes the encoders).
+ * ---------------------------------------------------------------------- */
+
+/* torch.nn.utils.weight_norm(dim=0): w = g*v/||v|| per output row of E = Cin*k
+ * elements (reference models/temporal_convolutional_model.py:24,30).  norm [rows] is saved
+ * for the backward, which returns dv [rows,E] and dg [rows]. */
+int cer_weight_norm_fwd(const float *v, const float *g, float *w, float *norm, int rows, int E, void *stream);
+int cer_weight_norm_bwd(const float *dw, const float *v, const float *g, const float *norm,
+                        float *dv, float *dg, int rows, int E, void *stream);
+
+/* Weight gradient of the causal dilated conv1d / linear layers:
+ * dW[co][ci][j] = sum_r dZ[r][co] * X[r-(k-1-j)*dil][ci], rows never cross a length-L sequence.
+ * dz [R,dz_ld], x [R,x_ld], dw [Cout,Cin,k] (torch layout).  Linear: k = 1. */
+int cer_conv1d_wgrad(const float *dz, int dz_ld, const float *x, int x_ld, float *dw,
+                     int R, int L, int Cout, int Cin, int k, int dil, void *stream);
+
+/* out[c] = sum_r a[r][c] * (b ? (b[r][c]-mean[c])*invstd[c] : 1); deterministic tree.
+ * Bias gradients and the BatchNorm / LayerNorm parameter gradients. */
+size_t cer_col_sum_workspace_bytes(int R, int C);
+int cer_col_sum(const float *a, int a_ld, const float *b, int b_ld, const float *mean, const float *invstd,
+                float *out, int R, int C, void *workspace, size_t workspace_bytes, void *stream);
+
+/* dz = dy * mask * leaky'(y) for y = mask*leaky(z)  (Dropout + LeakyReLU backward). */
+int cer_act_mask_bwd(const float *dy, const float *y, const float *mask, float *dz, size_t n, float slope, void *stream);
+/* TemporalBlock tail out = leaky(a2 + res), a2 = mask2*leaky(z2):
+ * du = dout*leaky'(out)  (gradient of res and of a2),  dz2 = du*mask2*leaky'(a2). */
+int cer_tblock_tail_bwd(const float *dout, const float *out, const float *a2, const float *mask2,
+                        float *du, float *dz2, size_t n, float slope, void *stream);
+
+/* BatchNorm1d over rows (reference models/model.py:475,515).  train != 0: batch statistics,
+ * running stats updated in place (unbiased variance, `momentum`), save_mean/save_invstd written.
+ * train == 0: running statistics. */
+int cer_bn_rows_fwd(const float *x, int x_ld, const float *w, const float *b, float *running_mean,
+                    float *running_var, float *save_mean, float *save_invstd, float *y, int y_ld,
+                    int R, int C, int train, float eps, float momentum, void *stream);
+int cer_bn_rows_bwd(const float *dy, int dy_ld, const float *x, int x_ld, const float *save_mean,
+                    const float *save_invstd, const float *w, float *dx, float *dw, float *db,
+                    int R, int C, int train, void *workspace, size_t workspace_bytes, void *stream);
+
+/* LFAN cross-modal attention core (reference models/transformer.py:11-19,133-159): for each
+ * (row, head) an M x M softmax over MODALITIES, vals = softmax(q k^T/sqrt(hd)) v + v.
+ * qkv[m] [R, H*3*hd] rows laid out [head][q|k|v]; vals [R, H*M*hd]; probs [R,H,M,M] saved. */
+int cer_lfan_attn_fwd(const float *const *qkv, float *vals, float *probs, int R, int H, int M, int hd, void *stream);
+int cer_lfan_attn_bwd(const float *const *qkv, const float *dvals, const float *probs, float *const *dqkv,
+                      int R, int H, int M, int hd, void *stream);
+
+/* y = LayerNorm(x*mask)*gamma+beta (mask = pre-scaled dropout mask or NULL), rows of C.
+ * Backward returns dx w.r.t. the un-masked x; scratch holds R*C floats. */
+int cer_layernorm_fwd(const float *x, const float *mask, const float *gamma, const float *beta, float *y, int y_ld,
+                      float *save_mean, float *save_rstd, int R, int C, float eps, void *stream);
+int cer_layernorm_bwd(const float *dy, int dy_ld, const float *x, const float *mask, const float *gamma,
+                      const float *save_mean, const float *save_rstd, float *dx, float *dgamma, float *dbeta,
+                      float *scratch, int R, int C, void *workspace, size_t workspace_bytes, void *stream);
+
+/* nn.CrossEntropyLoss(reduction='mean') on [R,C] logits with FLOAT labels cast to long
+ * (reference experiment.py:133, trainer.py:380-383); dlogits may be NULL. */
+int cer_cross_entropy(const float *logits, const float *labels, float *loss, float *dlogits, int R, int C, void *stream);
+
+/* Pre-scaled dropout keep-mask, a pure function of (seed, offset + i). */
+int cer_dropout_mask(float *mask, size_t n, float p, uint64_t seed, uint64_t offset, void *stream);
+
+/* y[r, 0:C] (pitch y_ld) = x[r, 0:C] (pitch x_ld). */
+int cer_copy_cols(const float *x, int x_ld, float *y, int y_ld, int R, int C, void *stream);
 
 #ifdef __cplusplus
 }
