@@ -1,0 +1,200 @@
+"""Training clips/sec of the hot path on N MI355X (one process per GPU, RCCL over xGMI).
+
+    python bench.py [--gpus N --steps K --warmup W] [--hw 224|40] [--batch 32] [--length 32]
+
+A step = one optimisation step of the tri-modal LFAN on one resident synthetic batch per
+rank: zero_grad -> IR-50 forward over B*L frames (frozen, fp32 MFMA) -> TCNs -> cross-modal
+fusion -> regressor -> cross-entropy -> backward through the trainable tail -> gradient
+all-reduce (N > 1) -> Nesterov SGD (reference trainer.py:345-391).  Prints ONE JSON line on
+rank 0.  `roofline` is measured live with HIP events around the IR-50 forward (all
+cer::conv_igemm_kernel launches, >99 % of the step's FLOPs); `cpu_baseline` times the CPU
+oracle on a bounded sample of the same workload on this box's host cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.modules.setdefault("triton", None)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+MODS = ["video", "vggish", "bert"]
+
+
+def ir50_forward_flops(hw):
+    """Algorithmic FLOPs (2/MAC) of one IR-50 frame: 52 convs + head FC."""
+    from feature_vs_text_compound_emotion_amd.synth import ir50_units
+    h = hw
+    macs = h * h * 64 * 3 * 9
+    for cin, depth, stride in ir50_units():
+        macs += h * h * depth * cin * 9            # conv1 3x3 s1 at input resolution
+        ho = (h - 1) // stride + 1
+        macs += ho * ho * depth * depth * 9        # conv2 3x3 stride s
+        if cin != depth:
+            macs += ho * ho * depth * cin          # 1x1 projection shortcut
+        h = ho
+    macs += 512 * h * h * 512                      # head FC
+    return 2.0 * macs
+
+
+def build_model(hw, length, device):
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.lfan import LFAN
+    sd = synth.lfan_state_dict(MODS, n_cls=7, head_hw=hw // 8, seed=0)
+    model = LFAN(backbone_settings={}, output_dim=7, task="CLASSIFICATION", modality=MODS, example_length=length,
+                 kernel_size=5, tcn_channel=synth.TCN_CHANNELS, root_dir="", device=device, head_hw=hw // 8)
+    model.init(load_backbone=False)
+    model.load_state_dict(sd, strict=True)
+    return model.to(device), sd
+
+
+def cpu_baseline(hw, length):
+    """CPU oracle, same step, bounded sample (about 10-30 s)."""
+    from feature_vs_text_compound_emotion_amd import synth
+    from oracle.lfan import cross_entropy_mean, lfan_forward, sgd_nesterov_step
+    threads = torch.get_num_threads()
+    sd = synth.lfan_state_dict(MODS, n_cls=7, head_hw=hw // 8, seed=0)
+    alias = synth.lfan_spec(MODS, head_hw=hw // 8)[1]
+    names = [k for k in sd if not k.startswith("spatial.") and k not in alias
+             and not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
+    clips, steps = (4, 3) if hw <= 64 else (1, 1)
+
+    def step(b, l, h, sdx):
+        xs, ls = synth.make_clip_batch(MODS, b, l, hw=h, seed=7)
+        params = [sdx[n].clone().requires_grad_(True) for n in names]
+        s = dict(sdx)
+        s.update(zip(names, params))
+        for a, src in alias.items():
+            s[a] = s[src]
+        loss = cross_entropy_mean(lfan_forward(xs, s, MODS, train=True, backbone_train=False), ls)
+        grads = torch.autograd.grad(loss, params)
+        sgd_nesterov_step([p.detach() for p in params], list(grads), [None] * len(params))
+        return loss.item()
+
+    warm_sd = synth.lfan_state_dict(MODS, n_cls=7, head_hw=5, seed=0) if hw != 40 else sd
+    step(1, length, 40, warm_sd)  # thread-pool / allocator warm-up, untimed
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step(clips, length, hw, sd)
+    dt = time.perf_counter() - t0
+    return {"value": clips * steps / dt, "unit": "clips/s", "cores": threads, "kind": "port",
+            "sample": f"{steps} train step(s) of {clips} clip(s) x {length} frames x {hw}x{hw} (tri-modal LFAN, "
+                      f"oracle on torch-CPU fp32, {threads} threads), {dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--hw", type=int, default=224, help="frame size: 224 (north-star shape) or 40 (reference crop)")
+    ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
+    ap.add_argument("--length", type=int, default=32)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    a = ap.parse_args()
+
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.data_parallel import ClipDataParallel, init_process_group_from_env
+    from feature_vs_text_compound_emotion_amd.lfan import cross_entropy_loss
+
+    rank, world, local = init_process_group_from_env()
+    if world != a.gpus:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP hot path has no CPU fallback")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    model, _ = build_model(a.hw, a.length, dev)
+    model.train()
+    ddp = ClipDataParallel(model, world_size=world)
+    opt = torch.optim.SGD(params=ddp.params, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=True)  # lr 1e-3 (F8)
+    x, labels = synth.make_clip_batch(MODS, a.batch, a.length, hw=a.hw, seed=1234 + rank)
+    x = {k: v.to(dev) for k, v in x.items()}
+    labels = labels.to(dev)
+
+    ev = []
+
+    def pre(mod, inp):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        ev.append([e, None])
+
+    def post(mod, inp, out):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        ev[-1][1] = e
+
+    model.spatial["visual"].register_forward_pre_hook(pre)
+    model.spatial["visual"].register_forward_hook(post)
+
+    def step():
+        ddp.zero_grad()
+        out = model(x)
+        loss = cross_entropy_loss(out, labels)
+        loss.backward()
+        ddp.all_reduce_gradients()
+        opt.step()
+        return loss
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    ev.clear()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = t.item()
+    enc_ms = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
+    frames = a.batch * a.length
+    flops = ir50_forward_flops(a.hw) * frames
+    achieved = flops / (enc_ms * 1e-3) / 1e12
+
+    if rank == 0:
+        res = {
+            "metric": "training clips/sec (32-frame tri-modal clip)",
+            "value": world * a.batch * a.steps / dt,
+            "unit": "clips/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": dt / a.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"LFAN tri-modal training step: frozen IR-50 forward on {a.batch}x{a.length} frames "
+                                   f"of {a.hw}x{a.hw} + TCN/fusion/regressor forward+backward + CE + Nesterov SGD; "
+                                   "vggish/bert as pre-computed per-frame features (as the reference trainer feeds them)",
+                       "clips_per_gpu": a.batch, "global_batch": a.batch * world, "frames_per_clip": a.length,
+                       "frame_hw": a.hw, "n_classes": 7, "parallelism": f"dp{world} over clips, flat-bucket RCCL all-reduce",
+                       "loss": float(loss.item())},
+            "roofline": {"bound": "mfma", "kernel": "cer::conv_igemm_kernel (IR-50 forward: 52 implicit-GEMM convs + head FC, "
+                                                    "v_mfma_f32_32x32x2_f32)",
+                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_flops_per_step": flops, "ms_per_step_in_kernel": enc_ms},
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(a.hw, a.length)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

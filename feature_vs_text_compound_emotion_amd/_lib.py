@@ -68,6 +68,10 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m feature_vs_text_compound_emotion_amd.build` "
             "(there is no CPU fallback for the HIP hot path)")
+    # torch bundles its own libamdhip64.so (SONAME libamdhip64.so.7).  Import torch FIRST so that
+    # our NEEDED libamdhip64.so.7 resolves to that already-loaded runtime; loading ours first
+    # would put a second HIP runtime (from /opt/rocm) in the process, which then sees no device.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in _SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the header and the library disagree

@@ -87,7 +87,7 @@ extern "C" int cer_pack_conv_weight(const float *w_oihw, const float *out_scale,
         return cer_set_error(CER_ERR_INVALID_ARG, "pack_conv_weight: bad argument");
     const int Kpad = cer_conv_kpad(KH, KW, transpose ? Cout : Cin);
     size_t n = (size_t)(transpose ? Cin : Cout) * Kpad;
-    hipLaunchKernelGGL(pack_conv_weight_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream,
+    CER_LAUNCH(pack_conv_weight_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        w_oihw, out_scale, w_packed, Cout, Cin, KH, KW, Kpad, flip, transpose);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
@@ -95,7 +95,7 @@ extern "C" int cer_pack_conv_weight(const float *w_oihw, const float *out_scale,
 
 extern "C" int cer_l2norm_rows(const float *x, float *y, int rows, int cols, void *stream) {
     if (!x || !y || rows <= 0 || cols <= 0) return cer_set_error(CER_ERR_INVALID_ARG, "l2norm_rows: bad argument");
-    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, rows, cols);
+    CER_LAUNCH(l2norm_rows_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, y, rows, cols);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }
@@ -104,7 +104,7 @@ extern "C" int cer_maxpool2x2_nhwc(const float *x, float *y, int N, int H, int W
     if (!x || !y || N <= 0 || H < 2 || W < 2 || C <= 0 || (C & 3) || (H & 1) || (W & 1))
         return cer_set_error(CER_ERR_INVALID_ARG, "maxpool2x2_nhwc: need even H, W and C % 4 == 0");
     size_t n = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-    hipLaunchKernelGGL(maxpool2x2_nhwc_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream,
+    CER_LAUNCH(maxpool2x2_nhwc_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, (hipStream_t)stream,
                        (const float4 *)x, (float4 *)y, N, H, W, C / 4);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;

@@ -18,3 +18,12 @@ int cer_set_error(int code, const char *fmt, ...);
 static inline unsigned cer_blocks(size_t n, unsigned per_block) {
     return (unsigned)((n + per_block - 1) / per_block);
 }
+
+// Launch with the thread's sticky HIP error cleared first, so that the hipGetLastError()
+// check after the launch reports THIS launch and not an unrelated earlier failure (e.g. a
+// device probe made before the process had initialised its GPU).
+#define CER_LAUNCH(...)                 \
+    do {                                \
+        (void)hipGetLastError();        \
+        hipLaunchKernelGGL(__VA_ARGS__); \
+    } while (0)

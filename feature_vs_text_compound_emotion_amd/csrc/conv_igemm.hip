@@ -346,11 +346,11 @@ static int launch_cfg(const ConvArgs &a, bool vec, hipStream_t st) {
     if (vec) {
         auto k = conv_igemm_kernel<BM, BN, WP, WC, true>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, grid, block, lds, st, a);
+        CER_LAUNCH(k, grid, block, lds, st, a);
     } else {
         auto k = conv_igemm_kernel<BM, BN, WP, WC, false>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        hipLaunchKernelGGL(k, grid, block, lds, st, a);
+        CER_LAUNCH(k, grid, block, lds, st, a);
     }
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
@@ -463,7 +463,7 @@ extern "C" int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const floa
     if (a.split_k > 1) {
         fin.split_k = a.split_k;
         size_t n = (size_t)a.M * ((a.Cout + 3) / 4);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fin,
+        CER_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fin,
                            (const float *)workspace);
         CER_HIP_CHECK(hipGetLastError());
     }

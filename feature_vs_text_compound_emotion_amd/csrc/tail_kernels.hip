@@ -394,7 +394,7 @@ using namespace cer;
 
 extern "C" int cer_weight_norm_fwd(const float *v, const float *g, float *w, float *norm, int rows, int E, void *stream) {
     if (!v || !g || !w || !norm || rows <= 0 || E <= 0) return cer_set_error(CER_ERR_INVALID_ARG, "weight_norm_fwd: bad argument");
-    hipLaunchKernelGGL(weight_norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, v, g, w, norm, rows, E);
+    CER_LAUNCH(weight_norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, v, g, w, norm, rows, E);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }
@@ -403,7 +403,7 @@ extern "C" int cer_weight_norm_bwd(const float *dw, const float *v, const float 
                                    float *dg, int rows, int E, void *stream) {
     if (!dw || !v || !g || !norm || !dv || !dg || rows <= 0 || E <= 0)
         return cer_set_error(CER_ERR_INVALID_ARG, "weight_norm_bwd: bad argument");
-    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, dw, v, g, norm, dv, dg, rows, E);
+    CER_LAUNCH(weight_norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, dw, v, g, norm, dv, dg, rows, E);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }
@@ -421,13 +421,13 @@ extern "C" int cer_col_sum(const float *a, int a_ld, const float *b, int b_ld, c
     const int slabs = (R + 255) / 256;
     dim3 grid((C + 31) / 32, slabs);
     if (slabs == 1) {
-        hipLaunchKernelGGL(col_sum_kernel, grid, dim3(256), 0, ST, a, a_ld, b, b_ld, mean, invstd, out, R, C, 256);
+        CER_LAUNCH(col_sum_kernel, grid, dim3(256), 0, ST, a, a_ld, b, b_ld, mean, invstd, out, R, C, 256);
     } else {
         if (!workspace || workspace_bytes < (size_t)slabs * C * sizeof(float))
             return cer_set_error(CER_ERR_WORKSPACE, "col_sum: workspace too small");
         float *part = (float *)workspace;
-        hipLaunchKernelGGL(col_sum_kernel, grid, dim3(256), 0, ST, a, a_ld, b, b_ld, mean, invstd, part, R, C, 256);
-        hipLaunchKernelGGL(col_sum_kernel, dim3((C + 31) / 32, 1), dim3(256), 0, ST, (const float *)part, C,
+        CER_LAUNCH(col_sum_kernel, grid, dim3(256), 0, ST, a, a_ld, b, b_ld, mean, invstd, part, R, C, 256);
+        CER_LAUNCH(col_sum_kernel, dim3((C + 31) / 32, 1), dim3(256), 0, ST, (const float *)part, C,
                            (const float *)nullptr, 0, (const float *)nullptr, (const float *)nullptr, out, slabs, C,
                            slabs);
     }
@@ -438,7 +438,7 @@ extern "C" int cer_col_sum(const float *a, int a_ld, const float *b, int b_ld, c
 extern "C" int cer_act_mask_bwd(const float *dy, const float *y, const float *mask, float *dz, size_t n, float slope,
                                 void *stream) {
     if (!dy || !y || !dz || n == 0 || (n & 3)) return cer_set_error(CER_ERR_INVALID_ARG, "act_mask_bwd: n must be a positive multiple of 4");
-    hipLaunchKernelGGL(act_mask_bwd_kernel, dim3(cer_blocks(n / 4, 256)), dim3(256), 0, ST, (const float4 *)dy,
+    CER_LAUNCH(act_mask_bwd_kernel, dim3(cer_blocks(n / 4, 256)), dim3(256), 0, ST, (const float4 *)dy,
                        (const float4 *)y, (const float4 *)mask, (float4 *)dz, n / 4, slope);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
@@ -448,7 +448,7 @@ extern "C" int cer_tblock_tail_bwd(const float *dout, const float *out, const fl
                                    float *du, float *dz2, size_t n, float slope, void *stream) {
     if (!dout || !out || !a2 || !du || !dz2 || n == 0 || (n & 3))
         return cer_set_error(CER_ERR_INVALID_ARG, "tblock_tail_bwd: n must be a positive multiple of 4");
-    hipLaunchKernelGGL(tblock_tail_bwd_kernel, dim3(cer_blocks(n / 4, 256)), dim3(256), 0, ST, (const float4 *)dout,
+    CER_LAUNCH(tblock_tail_bwd_kernel, dim3(cer_blocks(n / 4, 256)), dim3(256), 0, ST, (const float4 *)dout,
                        (const float4 *)out, (const float4 *)a2, (const float4 *)mask2, (float4 *)du, (float4 *)dz2,
                        n / 4, slope);
     CER_HIP_CHECK(hipGetLastError());
@@ -463,12 +463,12 @@ extern "C" int cer_bn_rows_fwd(const float *x, int x_ld, const float *w, const f
     const size_t n = (size_t)R * C;
     if (train) {
         if (!save_mean || !save_invstd) return cer_set_error(CER_ERR_INVALID_ARG, "bn_rows_fwd: train needs save buffers");
-        hipLaunchKernelGGL(bn_rows_stats_kernel, dim3((C + 31) / 32), dim3(256), 0, ST, x, x_ld, save_mean, save_invstd,
+        CER_LAUNCH(bn_rows_stats_kernel, dim3((C + 31) / 32), dim3(256), 0, ST, x, x_ld, save_mean, save_invstd,
                            running_mean, running_var, R, C, eps, momentum);
-        hipLaunchKernelGGL(bn_rows_apply_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, ST, x, x_ld,
+        CER_LAUNCH(bn_rows_apply_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, ST, x, x_ld,
                            (const float *)save_mean, (const float *)save_invstd, 0, eps, w, b, y, y_ld, R, C);
     } else {
-        hipLaunchKernelGGL(bn_rows_apply_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, ST, x, x_ld,
+        CER_LAUNCH(bn_rows_apply_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, ST, x, x_ld,
                            (const float *)running_mean, (const float *)running_var, 1, eps, w, b, y, y_ld, R, C);
     }
     CER_HIP_CHECK(hipGetLastError());
@@ -484,7 +484,7 @@ extern "C" int cer_bn_rows_bwd(const float *dy, int dy_ld, const float *x, int x
     if (rc) return rc;
     rc = cer_col_sum(dy, dy_ld, x, x_ld, save_mean, save_invstd, dw, R, C, workspace, workspace_bytes, stream);
     if (rc) return rc;
-    hipLaunchKernelGGL(bn_rows_bwd_kernel, dim3(cer_blocks((size_t)R * C, 256)), dim3(256), 0, ST, dy, dy_ld, x, x_ld,
+    CER_LAUNCH(bn_rows_bwd_kernel, dim3(cer_blocks((size_t)R * C, 256)), dim3(256), 0, ST, dy, dy_ld, x, x_ld,
                        save_mean, save_invstd, w, (const float *)db, (const float *)dw, dx, R, C, train);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
@@ -495,8 +495,8 @@ static void launch_attn(bool bwd, const FusionPtrs &P, float *vals, const float 
                         int M, hipStream_t st) {
     const size_t threads = (size_t)R * H * HD;
     dim3 grid(cer_blocks(threads, 256)), block(256);
-    if (!bwd) hipLaunchKernelGGL(lfan_attn_fwd_kernel<HD>, grid, block, 0, st, P, vals, probs, R, H, M);
-    else hipLaunchKernelGGL(lfan_attn_bwd_kernel<HD>, grid, block, 0, st, P, dvals, (const float *)probs, R, H, M);
+    if (!bwd) CER_LAUNCH(lfan_attn_fwd_kernel<HD>, grid, block, 0, st, P, vals, probs, R, H, M);
+    else CER_LAUNCH(lfan_attn_bwd_kernel<HD>, grid, block, 0, st, P, dvals, (const float *)probs, R, H, M);
 }
 
 static int attn_dispatch(bool bwd, const float *const *qkv, float *const *dqkv, float *vals, const float *dvals,
@@ -536,7 +536,7 @@ extern "C" int cer_layernorm_fwd(const float *x, const float *mask, const float 
                                  int y_ld, float *save_mean, float *save_rstd, int R, int C, float eps, void *stream) {
     if (!x || !gamma || !beta || !y || R <= 0 || C <= 0 || y_ld < C)
         return cer_set_error(CER_ERR_INVALID_ARG, "layernorm_fwd: bad argument");
-    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, ST, x, mask, gamma, beta, y, y_ld,
+    CER_LAUNCH(layernorm_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, ST, x, mask, gamma, beta, y, y_ld,
                        save_mean, save_rstd, R, C, eps);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
@@ -548,7 +548,7 @@ extern "C" int cer_layernorm_bwd(const float *dy, int dy_ld, const float *x, con
                                  void *stream) {
     if (!dy || !x || !gamma || !save_mean || !save_rstd || !dx || !dgamma || !dbeta || !scratch || R <= 0 || C <= 0)
         return cer_set_error(CER_ERR_INVALID_ARG, "layernorm_bwd: bad argument (scratch must hold R*C floats)");
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, ST, dy, dy_ld, x, mask, gamma, save_mean,
+    CER_LAUNCH(layernorm_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, ST, dy, dy_ld, x, mask, gamma, save_mean,
                        save_rstd, dx, scratch, R, C);
     CER_HIP_CHECK(hipGetLastError());
     int rc = cer_col_sum(scratch, C, nullptr, 0, nullptr, nullptr, dgamma, R, C, workspace, workspace_bytes, stream);
@@ -559,21 +559,21 @@ extern "C" int cer_layernorm_bwd(const float *dy, int dy_ld, const float *x, con
 extern "C" int cer_cross_entropy(const float *logits, const float *labels, float *loss, float *dlogits, int R, int C,
                                  void *stream) {
     if (!logits || !labels || !loss || R <= 0 || C <= 0) return cer_set_error(CER_ERR_INVALID_ARG, "cross_entropy: bad argument");
-    hipLaunchKernelGGL(cross_entropy_kernel, dim3(1), dim3(1024), 0, ST, logits, labels, loss, dlogits, R, C);
+    CER_LAUNCH(cross_entropy_kernel, dim3(1), dim3(1024), 0, ST, logits, labels, loss, dlogits, R, C);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }
 
 extern "C" int cer_dropout_mask(float *mask, size_t n, float p, uint64_t seed, uint64_t offset, void *stream) {
     if (!mask || n == 0 || !(p >= 0.f && p < 1.f)) return cer_set_error(CER_ERR_INVALID_ARG, "dropout_mask: need 0 <= p < 1");
-    hipLaunchKernelGGL(dropout_mask_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, ST, mask, n, p, seed, offset);
+    CER_LAUNCH(dropout_mask_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, ST, mask, n, p, seed, offset);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }
 
 extern "C" int cer_copy_cols(const float *x, int x_ld, float *y, int y_ld, int R, int C, void *stream) {
     if (!x || !y || R <= 0 || C <= 0 || x_ld < C || y_ld < C) return cer_set_error(CER_ERR_INVALID_ARG, "copy_cols: bad argument");
-    hipLaunchKernelGGL(copy_cols_kernel, dim3(cer_blocks((size_t)R * C, 256)), dim3(256), 0, ST, x, x_ld, y, y_ld, R, C);
+    CER_LAUNCH(copy_cols_kernel, dim3(cer_blocks((size_t)R * C, 256)), dim3(256), 0, ST, x, x_ld, y, y_ld, R, C);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }

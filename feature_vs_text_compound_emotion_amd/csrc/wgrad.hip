@@ -120,7 +120,7 @@ extern "C" int cer_conv1d_wgrad(const float *dz, int dz_ld, const float *x, int 
         return cer_set_error(CER_ERR_INVALID_ARG, "conv1d_wgrad: bad argument (R must be a multiple of L)");
     WgradArgs a{dz, x, dw, R, L, Cout, Cin, k, dil, dz_ld, x_ld};
     dim3 grid((Cout + WG_T - 1) / WG_T, (Cin + WG_T - 1) / WG_T, k);
-    hipLaunchKernelGGL(conv1d_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    CER_LAUNCH(conv1d_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }

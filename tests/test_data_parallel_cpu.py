@@ -1,0 +1,62 @@
+"""The N>1 data-parallel path on CPU: 2 gloo ranks, flat gradient bucket, mean all-reduce."""
+import os
+import socket
+
+import torch
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from feature_vs_text_compound_emotion_amd.data_parallel import ClipDataParallel, init_process_group_from_env
+    import torch.distributed as dist
+    r, w, _ = init_process_group_from_env(backend="gloo")
+    assert (r, w) == (rank, world)
+    torch.manual_seed(100 + rank)  # different init per rank: broadcast must make them equal
+    model = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.BatchNorm1d(5), torch.nn.Linear(5, 3))
+    model[0].weight.requires_grad = False  # a frozen part, like the encoders
+    ddp = ClipDataParallel(model)
+    g = torch.Generator().manual_seed(7)
+    xs, ys = torch.randn(8, 6, generator=g), torch.randint(0, 3, (8,), generator=g)
+    idx = ddp.shard(list(range(8)), rank)
+    opt = torch.optim.SGD(ddp.params, momentum=0.9, nesterov=True, weight_decay=1e-4)
+    for _ in range(2):
+        ddp.zero_grad()
+        loss = torch.nn.functional.cross_entropy(model(xs[idx]), ys[idx])
+        loss.backward()
+        assert all(p.grad.data_ptr() >= ddp.flat.data_ptr() for p in ddp.params)  # still views of the bucket
+        ddp.all_reduce_gradients()
+        opt.step()
+    out[rank] = {k: v.clone() for k, v in model.state_dict().items() if "running" not in k and "num_batches" not in k}
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_stay_in_lockstep_and_average_gradients():
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+        a, b = out[0], out[1]
+        for k in a:
+            assert torch.equal(a[k], b[k]), k
+
+
+def test_single_process_bucket_views_and_zero_grad():
+    from feature_vs_text_compound_emotion_amd.data_parallel import ClipDataParallel
+    model = torch.nn.Linear(4, 2)
+    ddp = ClipDataParallel(model, world_size=1)
+    model(torch.ones(3, 4)).sum().backward()
+    assert ddp.flat.abs().sum() > 0
+    assert model.weight.grad.data_ptr() == ddp.flat.data_ptr()
+    ddp.zero_grad()
+    assert ddp.flat.abs().sum() == 0 and model.weight.grad.abs().sum() == 0
