@@ -114,16 +114,20 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c,
     }
 }
 
-template <int BM, int BN, int WP, int WC, bool VEC>
+// VAR bit 0: s_setprio(1) around the MFMA cluster; bit 1: single LDS buffer (two barriers per
+// step, half the LDS -> more resident blocks per CU).
+template <int BM, int BN, int WP, int WC, bool VEC, int VAR>
 __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
+    constexpr bool PRIO = (VAR & 1) != 0, SINGLE = (VAR & 2) != 0;
+    constexpr int NBUF = SINGLE ? 1 : 2;
     static_assert(WP * WC == 4, "4 waves per block");
     constexpr int TP = BM / (32 * WP);  // 32-pixel MFMA tiles per wave
     constexpr int TC = BN / (32 * WC);  // 32-cout MFMA tiles per wave
     constexpr int XR = BM / 32;         // activation rows staged per thread
     constexpr int WR = BN / 32;         // weight rows staged per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Xs = smem;                      // [2][BM][PITCH]
-    float *Ws = smem + 2 * BM * PITCH;     // [2][BN][PITCH]
+    float *Xs = smem;                         // [NBUF][BM][PITCH]
+    float *Ws = smem + NBUF * BM * PITCH;     // [NBUF][BN][PITCH]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -259,8 +263,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
     __syncthreads();
 
     for (int s = s_begin; s < s_end; ++s) {
-        const int buf = (s - s_begin) & 1;
+        const int buf = SINGLE ? 0 : ((s - s_begin) & 1);
         if (s + 1 < s_end) load_step(s + 1);
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
         const float *xs = Xs + buf * BM * PITCH + (wp * TP * 32 + l31) * PITCH + half * 4;
         const float *ws = Ws + buf * BN * PITCH + (wc * TC * 32 + l31) * PITCH + half * 4;
 #pragma unroll
@@ -280,7 +285,9 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
                 }
         }
-        if (s + 1 < s_end) store_step(buf ^ 1);
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+        if constexpr (SINGLE) __syncthreads();  // everyone is done reading the only buffer
+        if (s + 1 < s_end) store_step(SINGLE ? 0 : (buf ^ 1));
         __syncthreads();
     }
 
@@ -339,16 +346,16 @@ __global__ void splitk_reduce_kernel(ConvArgs p, const float *partial) {
 // ---------------------------------------------------------------- host side
 struct TileCfg { int bm, bn; };
 
-template <int BM, int BN, int WP, int WC>
+template <int BM, int BN, int WP, int WC, int VAR>
 static int launch_cfg(const ConvArgs &a, bool vec, hipStream_t st) {
-    const size_t lds = (size_t)2 * (BM + BN) * PITCH * sizeof(float);
+    const size_t lds = (size_t)((VAR & 2) ? 1 : 2) * (BM + BN) * PITCH * sizeof(float);
     dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k), block(256);
     if (vec) {
-        auto k = conv_igemm_kernel<BM, BN, WP, WC, true>;
+        auto k = conv_igemm_kernel<BM, BN, WP, WC, true, VAR>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CER_LAUNCH(k, grid, block, lds, st, a);
     } else {
-        auto k = conv_igemm_kernel<BM, BN, WP, WC, false>;
+        auto k = conv_igemm_kernel<BM, BN, WP, WC, false, VAR>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CER_LAUNCH(k, grid, block, lds, st, a);
     }
@@ -356,22 +363,50 @@ static int launch_cfg(const ConvArgs &a, bool vec, hipStream_t st) {
     return CER_OK;
 }
 
+// Tile shapes: 1 = 128x128 (3 blocks/CU), 2 = 128x64 (4/CU), 4 = 64x128 (4/CU), 5 = 64x64 (5/CU);
+// all single-LDS-buffer + s_setprio (VAR 3, measured +15 % over double buffering because the
+// smaller LDS footprint admits one more block per CU).  Relative per-FLOP rates are measured
+// (tools/bench_conv.py); the picker minimises rounds x tile work, which matters when the grid is
+// only a few rounds deep (40x40 frames: 1600 tiles of 128x128 on 768 slots).
+struct TileInfo { int id, bm, bn, per_cu; float rate; };
+static const TileInfo kTiles[] = {{1, 128, 128, 3, 1.00f}, {2, 128, 64, 4, 0.93f}, {4, 64, 128, 4, 0.90f}, {5, 64, 64, 5, 0.75f}};
+
 static int pick_tile(const cer_conv_desc *d, int M) {
     if (d->tile) return d->tile;
-    // 1: 128x128   2: 128x64   3: 256x64   4: 64x128  5: 64x64
-    if (d->Cout <= 64) return M >= 256 * 256 ? 3 : (M >= 128 * 256 ? 2 : 5);
-    if ((long long)((M + 127) / 128) * ((d->Cout + 127) / 128) >= 256) return 1;
-    if (d->Cout <= 96) return 5;
-    return 4;
+    int best = 5;
+    float best_t = 3.4e38f;
+    for (const TileInfo &t : kTiles) {
+        if (t.bn > 64 && d->Cout <= 64) continue;
+        const long long blocks = (long long)((M + t.bm - 1) / t.bm) * ((d->Cout + t.bn - 1) / t.bn) * d->split_k;
+        const long long slots = 256ll * t.per_cu;
+        const long long rounds = (blocks + slots - 1) / slots;
+        // a partially filled round still runs at the per-block latency, but with fewer co-resident
+        // blocks each block runs a little faster: count it as at least half a round
+        const float frac = (float)(blocks - (rounds - 1) * slots) / (float)slots;
+        const float eff_rounds = (float)(rounds - 1) + (frac < 0.5f ? 0.5f + frac * 0.5f : (frac < 1.f ? 0.75f + frac * 0.25f : 1.f));
+        const float time = eff_rounds * (float)(t.bm * t.bn) * (float)t.per_cu / t.rate;
+        if (time < best_t) { best_t = time; best = t.id; }
+    }
+    return best;
 }
 
 static void tile_dims(int tile, int &bm, int &bn) {
     switch (tile) {
         case 1: bm = 128; bn = 128; break;
         case 2: bm = 128; bn = 64; break;
-        case 3: bm = 256; bn = 64; break;
         case 4: bm = 64; bn = 128; break;
         default: bm = 64; bn = 64; break;
+    }
+}
+
+template <int VAR>
+static int launch_shape(int shape, const ConvArgs &a, bool vec, hipStream_t st) {
+    switch (shape) {
+        case 1: return launch_cfg<128, 128, 2, 2, VAR>(a, vec, st);
+        case 2: return launch_cfg<128, 64, 2, 2, VAR>(a, vec, st);
+        case 4: return launch_cfg<64, 128, 1, 4, VAR>(a, vec, st);
+        case 5: return launch_cfg<64, 64, 2, 2, VAR>(a, vec, st);
+        default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: unknown tile id");
     }
 }
 
@@ -440,7 +475,7 @@ extern "C" int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const floa
     a.split_k = (a.steps + a.steps_per_split - 1) / a.steps_per_split;
     const int tile = pick_tile(d, a.M);
     int bm, bn;
-    tile_dims(tile, bm, bn);
+    tile_dims(tile % 10, bm, bn);
     a.tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = (a.Cout + bn - 1) / bn;
     hipStream_t st = (hipStream_t)stream;
@@ -451,13 +486,13 @@ extern "C" int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const floa
             return cer_set_error(CER_ERR_WORKSPACE, "conv2d_fwd: split-K workspace too small");
         a.y = (float *)workspace;
     }
-    switch (tile) {
-        case 1: rc = launch_cfg<128, 128, 2, 2>(a, vec, st); break;
-        case 2: rc = launch_cfg<128, 64, 2, 2>(a, vec, st); break;
-        case 3: rc = launch_cfg<256, 64, 4, 1>(a, vec, st); break;
-        case 4: rc = launch_cfg<64, 128, 1, 4>(a, vec, st); break;
-        case 5: rc = launch_cfg<64, 64, 2, 2>(a, vec, st); break;
-        default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: unknown tile id");
+    // tile = shape + 10*v: v = 0 -> shipped variant (single LDS buffer + setprio); v = 1 -> double
+    // buffered; v = 2 -> double buffered + setprio (kept for A/B measurements)
+    switch (tile / 10) {
+        case 0: rc = launch_shape<3>(tile % 10, a, vec, st); break;
+        case 1: rc = launch_shape<0>(tile % 10, a, vec, st); break;
+        case 2: rc = launch_shape<1>(tile % 10, a, vec, st); break;
+        default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: unknown tile variant");
     }
     if (rc) return rc;
     if (a.split_k > 1) {
