@@ -72,7 +72,7 @@ def cpu_baseline(hw, length):
         s.update(zip(names, params))
         for a, src in alias.items():
             s[a] = s[src]
-        loss = cross_entropy_mean(lfan_forward(xs, s, MODS, train=True, backbone_train=False), ls)
+        loss = cross_entropy_mean(lfan_forward(xs, s, MODS, train=True, backbone_train=True), ls)
         grads = torch.autograd.grad(loss, params)
         sgd_nesterov_step([p.detach() for p in params], list(grads), [None] * len(params))
         return loss.item()

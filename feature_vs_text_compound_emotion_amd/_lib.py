@@ -5,7 +5,8 @@ RuntimeError is raised.  ``load()`` only dlopens; compute entry points need a GP
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint64, c_void_p
+from ctypes import (POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_size_t, c_uint64,
+                    c_void_p)
 
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libcer_hip.so")
@@ -28,7 +29,12 @@ _SIGNATURES = {
     "cer_version": (c_int, []),
     "cer_conv_kpad": (c_int, [c_int, c_int, c_int]),
     "cer_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
-    "cer_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "cer_conv2d_stats_tiles": (c_int, [POINTER(ConvDesc)]),
+    "cer_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "cer_bn_finalize": (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, _P, _P, _P]),
+    "cer_bn_apply_stats_tiles": (c_int, [c_int]),
+    "cer_bn_apply_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, _P]),
     "cer_pack_conv_weight": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cer_weight_norm_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "cer_weight_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),

@@ -34,6 +34,7 @@ struct ConvArgs {
     const float *x, *w, *in_scale, *in_shift, *bias, *alpha, *res, *mask;
     float *y;        // output, or split-K partial slabs [split][M][Cout]
     float *aux;      // optional [M][Cout]: mask*act1(conv+bias), i.e. the value before the residual add
+    float *stats;    // optional [tiles_m][2][Cout]: per-tile sum / sum of squares of the RAW conv result
     int x_ld, y_ld;  // row pitches (floats) of x pixels / y rows
     int N, H, W, Cin, Ho, Wo, Cout;
     int KH, KW, stride, dil_h, dil_w, pad_t, pad_l;
@@ -319,6 +320,47 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
             });
         });
     });
+
+    // ---- optional per-channel batch statistics of the raw result (train-mode BatchNorm that
+    // follows this conv): deterministic per-tile partials, reduced later by bn_finalize ----
+    if (p.stats) {
+        float *red = smem;  // [WP][2][BN]; the K loop ended on a barrier, LDS is free
+        static_for<TC>([&](auto A) {
+            constexpr int a = decltype(A)::v;
+            static_for<16>([&](auto Rg) {
+                constexpr int r = decltype(Rg)::v;
+                float s1 = 0.f, s2 = 0.f;
+                static_for<TP>([&](auto B) {
+                    constexpr int b = decltype(B)::v;
+                    const int m = m0 + (wp * TP + b) * 32 + l31;
+                    const float v = (m < p.M) ? acc[a][b][r] : 0.f;
+                    s1 += v;
+                    s2 += v * v;
+                });
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) {
+                    s1 += __shfl_xor(s1, o);
+                    s2 += __shfl_xor(s2, o);
+                }
+                if (l31 == 0) {
+                    const int ci = (wc * TC + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    red[(wp * 2 + 0) * BN + ci] = s1;
+                    red[(wp * 2 + 1) * BN + ci] = s2;
+                }
+            });
+        });
+        __syncthreads();
+        if (tid < BN && c0 + tid < p.Cout) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WP; ++w) {
+                s1 += red[(w * 2 + 0) * BN + tid];
+                s2 += red[(w * 2 + 1) * BN + tid];
+            }
+            p.stats[((size_t)tile_m * 2 + 0) * p.Cout + c0 + tid] = s1;
+            p.stats[((size_t)tile_m * 2 + 1) * p.Cout + c0 + tid] = s2;
+        }
+    }
 }
 
 // Sum split-K slabs and apply the fused epilogue.  One thread per 4 couts.
@@ -431,6 +473,14 @@ static int validate_desc(const cer_conv_desc *d) {
     return CER_OK;
 }
 
+extern "C" int cer_conv2d_stats_tiles(const cer_conv_desc *d) {
+    if (!d || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
+    const int M = d->N * d->Ho * d->Wo;
+    int bm, bn;
+    tile_dims(pick_tile(d, M) % 10, bm, bn);
+    return (M + bm - 1) / bm;
+}
+
 extern "C" size_t cer_conv2d_workspace_bytes(const cer_conv_desc *d) {
     if (!d || d->split_k <= 1) return 0;
     return (size_t)d->split_k * d->N * d->Ho * d->Wo * d->Cout * sizeof(float);
@@ -439,7 +489,7 @@ extern "C" size_t cer_conv2d_workspace_bytes(const cer_conv_desc *d) {
 extern "C" int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const float *w,
                               const float *in_scale, const float *in_shift, const float *bias,
                               const float *alpha, const float *residual, const float *mask, float *y,
-                              float *aux, void *workspace, size_t workspace_bytes, void *stream) {
+                              float *aux, float *stats, void *workspace, size_t workspace_bytes, void *stream) {
     int rc = validate_desc(d);
     if (rc) return rc;
     if (!x || !w || !y) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: x, w, y must be non-NULL");
@@ -453,7 +503,9 @@ extern "C" int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const floa
     // the deepest input coordinate any output touches must be reachable (others are zero padding)
     ConvArgs a{};
     a.x = x; a.w = w; a.in_scale = in_scale; a.in_shift = in_shift; a.bias = bias; a.alpha = alpha;
-    a.res = residual; a.mask = mask; a.y = y; a.aux = aux;
+    a.res = residual; a.mask = mask; a.y = y; a.aux = aux; a.stats = stats;
+    if (stats && d->split_k > 1)
+        return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d_fwd: batch statistics are not available with split-K");
     a.x_ld = d->x_ld > 0 ? d->x_ld : d->Cin;
     a.y_ld = d->y_ld > 0 ? d->y_ld : d->Cout;
     if (a.x_ld < d->Cin || a.y_ld < d->Cout || ((d->Cin % 32) == 0 && (a.x_ld & 3) != 0))

@@ -1,0 +1,155 @@
+// encoder_bn.hip -- batch-statistics BatchNorm2d for the vision encoder in train mode.
+//
+// The reference calls model.train() on the whole LFAN (trainer.py:318), which also flips the
+// FROZEN IR-50's 53 BatchNorm2d layers to batch statistics and keeps updating their running
+// buffers.  To stay faithful without extra read passes, the producing kernels
+// emit deterministic per-tile partial sums (sum, sum of squares per channel): the conv epilogue
+// for raw conv results, bn_apply_nhwc for unit outputs.  bn_finalize reduces the partials in
+// double precision into a per-channel scale/shift and performs torch's running-stat update;
+// bn_apply_nhwc is the one bandwidth-bound pass per unit that normalises the conv result, adds
+// the (optionally normalised) shortcut and gathers the statistics of the sum for the next unit.
+#include "cer_internal.h"
+
+namespace cer {
+
+__global__ void bn_finalize_kernel(const float *__restrict__ partials, int tiles, int C, double count,
+                                   const float *__restrict__ gamma, const float *__restrict__ beta,
+                                   float *__restrict__ running_mean, float *__restrict__ running_var,
+                                   float momentum, float eps, float *__restrict__ scale, float *__restrict__ shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double s1 = 0.0, s2 = 0.0;
+    for (int t = 0; t < tiles; ++t) {
+        s1 += (double)partials[((size_t)t * 2 + 0) * C + c];
+        s2 += (double)partials[((size_t)t * 2 + 1) * C + c];
+    }
+    const double mean = s1 / count;
+    double var = s2 / count - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float sc = gamma[c] * (float)(1.0 / sqrt(var + (double)eps));
+    scale[c] = sc;
+    shift[c] = beta[c] - (float)mean * sc;
+    if (running_mean) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+}
+
+constexpr int APPLY_ROWS = 128;  // rows (pixels) per block
+
+struct ApplyArgs {
+    const float *y, *scale, *shift, *alpha, *res, *res_scale, *res_shift, *mask;
+    float *out, *stats;
+    int P, Ho, Wo, C, res_stride, Hr, Wr;
+};
+
+// Threads are laid out [rows_per_pass][C/4]; each thread keeps its 4 channels for the whole block
+// so the channel statistics accumulate in registers and meet in LDS once at the end.
+__global__ __launch_bounds__(256) void bn_apply_nhwc_kernel(ApplyArgs p) {
+    __shared__ float red[2][256][4];
+    const int c4n = p.C >> 2;                    // float4 per row (16..128)
+    const int rpp = 256 / c4n;                   // rows per pass
+    const int tc = threadIdx.x % c4n, tr = threadIdx.x / c4n;
+    const int c = tc * 4;
+    const bool active = tr < rpp;
+    const float4 sc = *reinterpret_cast<const float4 *>(p.scale + c);
+    const float4 sh = *reinterpret_cast<const float4 *>(p.shift + c);
+    float4 al = make_float4(1, 1, 1, 1), rs = make_float4(1, 1, 1, 1), rt = make_float4(0, 0, 0, 0);
+    if (p.alpha) al = *reinterpret_cast<const float4 *>(p.alpha + c);
+    if (p.res_scale) {
+        rs = *reinterpret_cast<const float4 *>(p.res_scale + c);
+        rt = *reinterpret_cast<const float4 *>(p.res_shift + c);
+    }
+    float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
+    const int row0 = blockIdx.x * APPLY_ROWS;
+    if (active) {
+        for (int r = row0 + tr; r < min(p.P, row0 + APPLY_ROWS); r += rpp) {
+            const size_t off = (size_t)r * p.C + c;
+            float4 v = *reinterpret_cast<const float4 *>(p.y + off);
+            float o[4] = {v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w};
+            if (p.alpha) {
+                o[0] = o[0] >= 0.f ? o[0] : o[0] * al.x; o[1] = o[1] >= 0.f ? o[1] : o[1] * al.y;
+                o[2] = o[2] >= 0.f ? o[2] : o[2] * al.z; o[3] = o[3] >= 0.f ? o[3] : o[3] * al.w;
+            }
+            if (p.mask) {
+                const float4 m = *reinterpret_cast<const float4 *>(p.mask + off);
+                o[0] *= m.x; o[1] *= m.y; o[2] *= m.z; o[3] *= m.w;
+            }
+            if (p.res) {
+                size_t roff;
+                if (p.res_stride == 1 && p.Hr == p.Ho && p.Wr == p.Wo) {
+                    roff = off;
+                } else {
+                    const int hw = p.Ho * p.Wo;
+                    const int n = r / hw, q = r - n * hw;
+                    const int ho = q / p.Wo, wo = q - ho * p.Wo;
+                    roff = ((size_t)(n * p.Hr + ho * p.res_stride) * p.Wr + wo * p.res_stride) * p.C + c;
+                }
+                const float4 x = *reinterpret_cast<const float4 *>(p.res + roff);
+                o[0] += x.x * rs.x + rt.x; o[1] += x.y * rs.y + rt.y;
+                o[2] += x.z * rs.z + rt.z; o[3] += x.w * rs.w + rt.w;
+            }
+            *reinterpret_cast<float4 *>(p.out + off) = make_float4(o[0], o[1], o[2], o[3]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { s1[e] += o[e]; s2[e] += o[e] * o[e]; }
+        }
+    }
+    if (!p.stats) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
+    __syncthreads();
+    if (threadIdx.x < c4n) {
+        float a1[4] = {0, 0, 0, 0}, a2[4] = {0, 0, 0, 0};
+        for (int t = 0; t < rpp; ++t) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                a1[e] += red[0][t * c4n + threadIdx.x][e];
+                a2[e] += red[1][t * c4n + threadIdx.x][e];
+            }
+        }
+        float *dst = p.stats + (size_t)blockIdx.x * 2 * p.C;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            dst[threadIdx.x * 4 + e] = a1[e];
+            dst[p.C + threadIdx.x * 4 + e] = a2[e];
+        }
+    }
+}
+
+}  // namespace cer
+
+using namespace cer;
+
+extern "C" int cer_bn_finalize(const float *partials, int tiles, int C, double count, const float *gamma,
+                               const float *beta, float *running_mean, float *running_var, float momentum, float eps,
+                               float *scale, float *shift, void *stream) {
+    if (!partials || tiles <= 0 || C <= 0 || !(count > 0) || !gamma || !beta || !scale || !shift ||
+        ((running_mean == nullptr) != (running_var == nullptr)))
+        return cer_set_error(CER_ERR_INVALID_ARG, "bn_finalize: bad argument");
+    CER_LAUNCH(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partials, tiles, C, count,
+               gamma, beta, running_mean, running_var, momentum, eps, scale, shift);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+extern "C" int cer_bn_apply_stats_tiles(int P) { return P > 0 ? (P + APPLY_ROWS - 1) / APPLY_ROWS : 0; }
+
+extern "C" int cer_bn_apply_nhwc(const float *y, const float *scale, const float *shift, const float *alpha,
+                                 const float *res, const float *res_scale, const float *res_shift, const float *mask,
+                                 float *out, float *stats, int N, int Ho, int Wo, int C, int res_stride, int Hr, int Wr,
+                                 void *stream) {
+    if (!y || !scale || !shift || !out || N <= 0 || Ho <= 0 || Wo <= 0 || C < 4 || C > 1024 || (C & 3) ||
+        (256 % (C / 4)) != 0)
+        return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc: C must be 16..1024 with C/4 dividing 256");
+    if ((long long)N * Ho * Wo >= (1ll << 31)) return cer_set_error(CER_ERR_UNSUPPORTED, "bn_apply_nhwc: too many pixels");
+    if ((res_scale == nullptr) != (res_shift == nullptr) || (res_scale && !res))
+        return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc: residual affine needs res, res_scale and res_shift");
+    if (res && (res_stride <= 0 || (Ho - 1) * res_stride >= Hr || (Wo - 1) * res_stride >= Wr))
+        return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc: residual geometry out of range");
+    ApplyArgs a{y, scale, shift, alpha, res, res_scale, res_shift, mask, out, stats,
+                N * Ho * Wo, Ho, Wo, C, res_stride, Hr, Wr};
+    CER_LAUNCH(bn_apply_nhwc_kernel, dim3(cer_bn_apply_stats_tiles(a.P)), dim3(256), 0, (hipStream_t)stream, a);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}

@@ -229,7 +229,9 @@ class LFAN(nn.Module):
             if m == "video":
                 bsz, length = x.shape[0], x.shape[1]
                 with torch.no_grad():
-                    emb = self.spatial["visual"](x.reshape(-1, *x.shape[2:]))
+                    vis = self.spatial["visual"]
+                    vis.backbone.dropout_seed = self.dropout_seed
+                    emb = vis(x.reshape(-1, *x.shape[2:]), masks.get("head"))
                 rows_in[m] = emb
             else:
                 bsz, length = x.shape[0], x.shape[2]

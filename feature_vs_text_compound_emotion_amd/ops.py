@@ -54,7 +54,7 @@ def pack_conv_weight(w_oihw, out_scale=None, flip=False, transpose=False):
 def conv2d(x, w_packed, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, in_scale=None,
            in_shift=None, bias=None, alpha=None, residual=None, res_stride=1, mask=None, act1=ACT_NONE,
            act2=ACT_NONE, slope=LEAKY_SLOPE, split_k=1, x_nchw=False, tile=0, out=None, aux=None, x_ld=0, y_ld=0,
-           x_shape=None):
+           x_shape=None, want_stats=False):
     """y[N,Ho,Wo,Cout] = act2(mask*act1(conv(affine(x), w)+bias) + residual).  x is NHWC
     (or NCHW with ``x_nchw`` on the small-Cin path).  ``x_shape`` = (N,H,W,Cin) overrides
     x.shape when x is a column slice (then ``x_ld`` is its row pitch)."""
@@ -103,10 +103,11 @@ def conv2d(x, w_packed, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None
         _dev_f32(out, "out", contiguous=(y_ld == 0))
     ws_bytes = lib.cer_conv2d_workspace_bytes(ctypes.byref(d))
     ws = _empty((ws_bytes // 4,), x) if ws_bytes else None
+    stats = _empty((lib.cer_conv2d_stats_tiles(ctypes.byref(d)), 2, cout), x) if want_stats else None
     check(lib.cer_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_packed), ptr(in_scale), ptr(in_shift), ptr(bias),
-                             ptr(alpha), ptr(residual), ptr(mask), ptr(out), ptr(aux), ptr(ws), ws_bytes,
+                             ptr(alpha), ptr(residual), ptr(mask), ptr(out), ptr(aux), ptr(stats), ptr(ws), ws_bytes,
                              current_stream()), "cer_conv2d_fwd")
-    return out
+    return (out, stats) if want_stats else out
 
 
 def linear(x2d, w_packed, bias=None, act=ACT_NONE, split_k=1, residual=None, out=None):
@@ -138,6 +139,37 @@ def maxpool2x2_nhwc(x):
     y = _empty((n, h // 2, w // 2, c), x)
     check(_lib.load().cer_maxpool2x2_nhwc(ptr(x), ptr(y), n, h, w, c, current_stream()), "cer_maxpool2x2_nhwc")
     return y
+
+
+# ------------------------------------------------------------------ train-mode BatchNorm2d (encoder)
+def bn_finalize(partials, count, gamma, beta, running_mean=None, running_var=None, momentum=0.1, eps=1e-5):
+    """[tiles,2,C] partial sums -> (scale, shift) of the batch-statistics BatchNorm; running stats
+    are updated in place like torch does in train mode."""
+    _dev_f32(partials, "partials")
+    tiles, _, c = partials.shape
+    scale, shift = _empty((c,), partials), _empty((c,), partials)
+    check(_lib.load().cer_bn_finalize(ptr(partials), tiles, c, float(count), ptr(gamma), ptr(beta),
+                                      ptr(running_mean), ptr(running_var), momentum, eps, ptr(scale), ptr(shift),
+                                      current_stream()), "cer_bn_finalize")
+    return scale, shift
+
+
+def bn_apply_nhwc(y, scale, shift, alpha=None, res=None, res_stride=1, res_scale=None, res_shift=None, mask=None,
+                  want_stats=False):
+    """out = mask*prelu(y*scale+shift) + (res*res_scale+res_shift) on NHWC; optionally the partial
+    statistics of ``out`` for the next BatchNorm."""
+    for t, nme in ((y, "y"), (scale, "scale"), (shift, "shift"), (alpha, "alpha"), (res, "res"),
+                   (res_scale, "res_scale"), (res_shift, "res_shift"), (mask, "mask")):
+        _dev_f32(t, nme)
+    n, ho, wo, c = y.shape
+    lib = _lib.load()
+    out = torch.empty_like(y)
+    stats = _empty((lib.cer_bn_apply_stats_tiles(n * ho * wo), 2, c), y) if want_stats else None
+    hr, wr = (res.shape[1], res.shape[2]) if res is not None else (0, 0)
+    check(lib.cer_bn_apply_nhwc(ptr(y), ptr(scale), ptr(shift), ptr(alpha), ptr(res), ptr(res_scale), ptr(res_shift),
+                                ptr(mask), ptr(out), ptr(stats), n, ho, wo, c, res_stride, hr, wr, current_stream()),
+          "cer_bn_apply_nhwc")
+    return (out, stats) if want_stats else out
 
 
 # ------------------------------------------------------------------ trainable tail

@@ -14,6 +14,8 @@ The torch.nn layers below only HOLD parameters (so keys, ``.to()``,
 ``deepcopy`` and ``requires_grad`` behave like the reference); their own
 ``forward`` is never called.
 """
+import copy
+
 import torch
 from torch import nn
 
@@ -56,6 +58,23 @@ class IR50(nn.Module):
         self.body = nn.Sequential(*[_Unit(*u) for u in ir50_units()])
         self._packed = None
         self._packed_key = None
+        self._packed_train = None
+        self._packed_train_key = None
+        self.bn_mode = "reference"  # or "frozen": encoder BatchNorm/Dropout stay in eval behaviour under train()
+        self.dropout_seed = 0
+        self._dropout_calls = 0
+
+    def __deepcopy__(self, memo):
+        """trainer.py:656,705 deep-copies the model: copy parameters/buffers, not the packed caches."""
+        caches = (self._packed, self._packed_train)
+        self._packed = self._packed_train = None
+        try:
+            new = self.__class__.__new__(self.__class__)
+            memo[id(self)] = new
+            new.__dict__ = copy.deepcopy(self.__dict__, memo)
+        finally:
+            self._packed, self._packed_train = caches
+        return new
 
     # ------------------------------------------------------------------ packing
     @staticmethod
@@ -107,14 +126,91 @@ class IR50(nn.Module):
         self._packed, self._packed_key = P, key
         return P
 
+    def pack_train(self):
+        """Raw (un-folded) kernel layouts for the batch-statistics path; weights are frozen, so this
+        is cached on the parameter versions only."""
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed_train is not None and key == self._packed_train_key:
+            return self._packed_train
+        dev = self.input_layer[0].weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("IR50 runs on the HIP kernels only: move the module to a GPU (no CPU fallback)")
+        P = {"stem_w": ops.pack_conv_weight(self.input_layer[0].weight.detach().contiguous()), "units": []}
+        for u in self.body:
+            d = {"w1": ops.pack_conv_weight(u.res_layer[1].weight.detach().contiguous()),
+                 "w2": ops.pack_conv_weight(u.res_layer[3].weight.detach().contiguous())}
+            if u.cin != u.depth:
+                d["ws"] = ops.pack_conv_weight(u.shortcut_layer[0].weight.detach().contiguous())
+            P["units"].append(d)
+        fc, hw = self.output_layer[3], self.head_hw
+        P["head_w"] = fc.weight.detach().view(fc.out_features, -1, hw * hw).permute(0, 2, 1).contiguous().view(
+            fc.out_features, -1)  # K order (c,h,w) -> (h,w,c)
+        self._packed_train, self._packed_train_key = P, key
+        return P
+
     # ------------------------------------------------------------------ forward
-    def forward(self, x):
-        """x: [N,3,H,W] float32 on the GPU -> [N,512], rows of unit L2 norm."""
-        if self.training and any(isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d)) for m in [self.input_layer[1]]):
-            # Batch-statistic BatchNorm / Dropout inside the frozen encoder (what the reference's
-            # model.train() does, SURVEY.md F6) is not on the HIP path yet: the encoder always
-            # runs with running statistics.  Documented deviation (DESIGN.md).
-            pass
+    def _head_split_k(self, n, k):
+        tiles = ((n + 127) // 128) * 4
+        return max(1, min(k // 32, (768 + tiles - 1) // tiles))
+
+    def _finalize(self, stats, count, bn):
+        return ops.bn_finalize(stats, count, bn.weight.detach(), bn.bias.detach(), bn.running_mean, bn.running_var,
+                               momentum=bn.momentum, eps=bn.eps)
+
+    def _forward_batch_stats(self, x, head_mask=None):
+        """Reference train() semantics: every BatchNorm uses batch statistics over the N frames and
+        updates its running buffers; Dropout(0.4) before the head FC.  ``head_mask`` ([N,h,w,512],
+        pre-scaled) overrides the generated dropout mask (parity tests)."""
+        P = self.pack_train()
+        self._packed = None  # running statistics are about to change: the folded eval weights go stale
+        n = x.shape[0]
+        y0, st = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True)
+        s, t = self._finalize(st, y0.numel() // 64, self.input_layer[1])
+        y, xst = ops.bn_apply_nhwc(y0, s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True)
+        del y0
+        for u, d in zip(self.body, P["units"]):
+            s1, t1 = self._finalize(xst, y.numel() // u.cin, u.res_layer[0])
+            tt = ops.conv2d(y, d["w1"], 3, 3, pad=(1, 1), in_scale=s1, in_shift=t1,
+                            alpha=u.res_layer[2].weight.detach(), act1=ops.ACT_PRELU)
+            z, zst = ops.conv2d(tt, d["w2"], 3, 3, stride=u.stride, pad=(1, 1), want_stats=True)
+            del tt
+            cnt = z.numel() // u.depth
+            s2, t2 = self._finalize(zst, cnt, u.res_layer[4])
+            if u.cin != u.depth:
+                sz, sst = ops.conv2d(y, d["ws"], 1, 1, stride=u.stride, want_stats=True)
+                ss, stt = self._finalize(sst, cnt, u.shortcut_layer[1])
+                y, xst = ops.bn_apply_nhwc(z, s2, t2, res=sz, res_scale=ss, res_shift=stt, want_stats=True)
+            else:
+                y, xst = ops.bn_apply_nhwc(z, s2, t2, res=y, res_stride=u.stride, want_stats=True)
+            del z
+        nn_, h, w, c = y.shape
+        if h != self.head_hw or w != self.head_hw:
+            raise RuntimeError(f"IR50 head was built for {self.head_hw}x{self.head_hw} feature maps but got {h}x{w}")
+        s0, t0 = self._finalize(xst, y.numel() // c, self.output_layer[0])
+        p_drop = self.output_layer[1].p
+        if head_mask is None and p_drop > 0:
+            self._dropout_calls += 1
+            head_mask = ops.dropout_mask(tuple(y.shape), p_drop, 0x1f50 + self.dropout_seed, self._dropout_calls * y.numel(),
+                                         y.device)
+        hfeat = ops.bn_apply_nhwc(y, s0, t0, mask=head_mask)
+        k = h * w * c
+        fc, bn1 = self.output_layer[3], self.output_layer[4]
+        e = ops.linear(hfeat.view(n, k), P["head_w"], bias=fc.bias.detach(), split_k=self._head_split_k(n, k))
+        e, _, _ = ops.bn_rows_fwd(e, bn1.weight.detach(), bn1.bias.detach(), bn1.running_mean, bn1.running_var, True,
+                                  bn1.eps, bn1.momentum)
+        torch._foreach_add_([m.num_batches_tracked for m in self.modules()
+                             if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d))], 1)
+        return ops.l2norm_rows(e)
+
+    def forward(self, x, head_mask=None):
+        """x: [N,3,H,W] float32 on the GPU -> [N,512], rows of unit L2 norm.
+
+        eval(): running statistics, every BatchNorm folded into the conv kernels (fast path).
+        train(): ``bn_mode == "reference"`` reproduces the reference, whose model.train() also puts
+        this frozen encoder's BatchNorm/Dropout layers in train mode (SURVEY.md F6);
+        ``bn_mode == "frozen"`` keeps the encoder in eval behaviour (common practice, faster)."""
+        if self.training and self.bn_mode == "reference":
+            return self._forward_batch_stats(x, head_mask)
         P = self.pack()
         x = x.contiguous()
         y = ops.conv2d(x, P["stem_w"], 3, 3, pad=(1, 1), bias=P["stem_b"], alpha=P["stem_a"],
@@ -133,9 +229,7 @@ class IR50(nn.Module):
             raise RuntimeError(f"IR50 head was built for {self.head_hw}x{self.head_hw} feature maps "
                                f"({8 * self.head_hw}x{8 * self.head_hw} frames) but got {h}x{w}")
         k = h * w * c
-        tiles = ((n + 127) // 128) * 4
-        split_k = max(1, min(k // 32, (512 + tiles - 1) // tiles))
-        e = ops.linear(y.view(n, k), P["head_w"], bias=P["head_b"], split_k=split_k)
+        e = ops.linear(y.view(n, k), P["head_w"], bias=P["head_b"], split_k=self._head_split_k(n, k))
         return ops.l2norm_rows(e)
 
 
@@ -169,8 +263,8 @@ class VisualBackbone(nn.Module):
         nn.init.xavier_uniform_(self.logits.weight)
         nn.init.constant_(self.logits.bias, 0)
 
-    def forward(self, x):
-        return self.backbone(x)
+    def forward(self, x, head_mask=None):
+        return self.backbone(x, head_mask)
 
     def extract(self, x):
         return self.backbone(x)

@@ -64,6 +64,9 @@ int cer_version(void);
  *   mask     [N,Ho,Wo,Cout] or NULL (pre-scaled dropout mask)
  *   aux      [N,Ho,Wo,Cout] or NULL: receives mask*act1(conv+bias), the value before
  *            the residual add (saved for the backward pass of a TemporalBlock)
+ *   stats    [cer_conv2d_stats_tiles(d)][2][Cout] or NULL: per-tile sum and sum of squares
+ *            of the RAW conv result over valid pixels (deterministic partials for the
+ *            train-mode BatchNorm that follows; reduce with cer_bn_finalize)
  *   split_k  >= 1; > 1 needs `workspace` of cer_conv2d_workspace_bytes()
  * ---------------------------------------------------------------------- */
 typedef struct cer_conv_desc {
@@ -82,11 +85,12 @@ typedef struct cer_conv_desc {
 
 int cer_conv_kpad(int KH, int KW, int Cin);
 size_t cer_conv2d_workspace_bytes(const cer_conv_desc *d);
+int cer_conv2d_stats_tiles(const cer_conv_desc *d);
 int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const float *w,
                    const float *in_scale, const float *in_shift,
                    const float *bias, const float *alpha,
                    const float *residual, const float *mask,
-                   float *y, float *aux, void *workspace, size_t workspace_bytes, void *stream);
+                   float *y, float *aux, float *stats, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Pack an OIHW (torch) conv weight into [Cout][Kpad] with optional per-output
  * scale (BatchNorm fold).  w_oihw [Cout,Cin,KH,KW]; out_scale [Cout] or NULL.
@@ -162,6 +166,23 @@ int cer_layernorm_bwd(const float *dy, int dy_ld, const float *x, const float *m
 /* nn.CrossEntropyLoss(reduction='mean') on [R,C] logits with FLOAT labels cast to long
  * (reference experiment.py:133, trainer.py:380-383); dlogits may be NULL. */
 int cer_cross_entropy(const float *logits, const float *labels, float *loss, float *dlogits, int R, int C, void *stream);
+
+/* Train-mode BatchNorm2d inside the vision encoder (the reference's model.train() also puts
+ * the frozen IR-50's BatchNorms in batch-statistics mode).
+ * cer_bn_finalize: reduce `tiles` partial rows [tiles][2][C] (sum, sum of squares over `count`
+ * elements per channel) in double precision -> scale = gamma*invstd, shift = beta - mean*scale;
+ * updates running_mean/var in place (unbiased variance, `momentum`) when non-NULL.
+ * cer_bn_apply_nhwc: out = mask * prelu(y*scale+shift) + (res*res_scale+res_shift), residual
+ * sampled with res_stride like the conv epilogue; optionally emits the partial statistics of
+ * `out` ([cer_bn_apply_stats_tiles(P)][2][C]) for the next BatchNorm. */
+int cer_bn_finalize(const float *partials, int tiles, int C, double count, const float *gamma, const float *beta,
+                    float *running_mean, float *running_var, float momentum, float eps,
+                    float *scale, float *shift, void *stream);
+int cer_bn_apply_stats_tiles(int P);
+int cer_bn_apply_nhwc(const float *y, const float *scale, const float *shift, const float *alpha,
+                      const float *res, const float *res_scale, const float *res_shift, const float *mask,
+                      float *out, float *stats, int N, int Ho, int Wo, int C, int res_stride, int Hr, int Wr,
+                      void *stream);
 
 /* Pre-scaled dropout keep-mask, a pure function of (seed, offset + i). */
 int cer_dropout_mask(float *mask, size_t n, float p, uint64_t seed, uint64_t offset, void *stream);

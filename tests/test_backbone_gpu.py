@@ -59,3 +59,47 @@ def test_wrong_frame_size_raises():
     vb = _build(vsd, 5)
     with pytest.raises(RuntimeError):
         vb(torch.zeros(1, 3, 48, 48, device="cuda"))
+
+
+@pytest.mark.parametrize("n,hw", [(6, 40), (2, 64)])
+def test_train_mode_batch_statistics_match_oracle(n, hw):
+    """model.train() semantics of the reference: batch-stat BatchNorm in all 54 layers,
+    running buffers updated, Dropout(0.4) mask before the FC (mask injected for parity)."""
+    import oracle
+    from feature_vs_text_compound_emotion_amd import synth
+    vsd = synth.make_state_dict(synth.visual_backbone_spec("", hw // 8), seed=13)
+    g = torch.Generator().manual_seed(n * hw)
+    frames = torch.randn(n, 3, hw, hw, generator=g)
+    mask = synth.dropout_mask((n, 512, hw // 8, hw // 8), 0.4, g)
+    nb = {}
+    with torch.no_grad():
+        ref = oracle.ir50_forward(frames, vsd, "backbone.", train=True, head_dropout_mask=mask, new_buffers=nb)
+    vb = _build(vsd, hw // 8).train()
+    with torch.no_grad():
+        emb = vb(frames.cuda(), mask.permute(0, 2, 3, 1).contiguous().cuda()).cpu()
+    assert (emb - ref).abs().max().item() < 2e-4
+    sd_after = vb.state_dict()
+    assert len(nb) == 2 * 54
+    worst = max((sd_after[k].cpu() - v).abs().max().item() for k, v in nb.items())
+    assert worst < 2e-5, worst
+    assert int(sd_after["backbone.input_layer.1.num_batches_tracked"]) == 1
+    # the folded eval weights must pick up the updated running statistics
+    vb.eval()
+    sd_new = {k: v.cpu() for k, v in sd_after.items()}
+    with torch.no_grad():
+        ref_eval = oracle.ir50_forward(frames, sd_new, "backbone.")
+        emb_eval = vb(frames.cuda()).cpu()
+    assert (emb_eval - ref_eval).abs().max().item() < EMB_TOL
+
+
+def test_frozen_bn_mode_keeps_eval_behaviour_under_train():
+    import oracle
+    from feature_vs_text_compound_emotion_amd import synth
+    vsd = synth.make_state_dict(synth.visual_backbone_spec("", 5), seed=14)
+    frames = torch.randn(3, 3, 40, 40, generator=torch.Generator().manual_seed(3))
+    vb = _build(vsd, 5).train()
+    vb.backbone.bn_mode = "frozen"
+    with torch.no_grad():
+        emb = vb(frames.cuda()).cpu()
+        ref = oracle.ir50_forward(frames, vsd, "backbone.")
+    assert (emb - ref).abs().max().item() < EMB_TOL
