@@ -31,7 +31,9 @@ _SIGNATURES = {
     "cer_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "cer_conv2d_stats_tiles": (c_int, [POINTER(ConvDesc)]),
     "cer_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
-    "cer_bn_finalize": (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, _P, _P, _P]),
+    "cer_bn_finalize_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "cer_bn_finalize": (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, c_size_t,
+                                _P]),
     "cer_bn_apply_stats_tiles": (c_int, [c_int]),
     "cer_bn_apply_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, _P]),

@@ -12,16 +12,32 @@
 
 namespace cer {
 
-__global__ void bn_finalize_kernel(const float *__restrict__ partials, int tiles, int C, double count,
+// Stage A: G blocks each fold a contiguous run of partial rows into one double-precision row
+// (threads run across channels, so every load is coalesced).  Stage B: one thread per channel
+// folds the G rows and produces scale/shift + the running-stat update.  Fixed order -> deterministic.
+constexpr int FIN_MAX_GROUPS = 512;
+
+__global__ void bn_partial_reduce_kernel(const float *__restrict__ partials, int tiles, int C, int rows_per_group,
+                                         double *__restrict__ out) {
+    const int g = blockIdx.x;
+    const int t0 = g * rows_per_group, t1 = min(tiles, t0 + rows_per_group);
+    for (int c = threadIdx.x; c < 2 * C; c += blockDim.x) {  // 2*C contiguous floats per partial row
+        double s = 0.0;
+        for (int t = t0; t < t1; ++t) s += (double)partials[(size_t)t * 2 * C + c];
+        out[(size_t)g * 2 * C + c] = s;
+    }
+}
+
+__global__ void bn_finalize_kernel(const double *__restrict__ groups, int ngroups, int C, double count,
                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float *__restrict__ running_mean, float *__restrict__ running_var,
                                    float momentum, float eps, float *__restrict__ scale, float *__restrict__ shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int t = 0; t < tiles; ++t) {
-        s1 += (double)partials[((size_t)t * 2 + 0) * C + c];
-        s2 += (double)partials[((size_t)t * 2 + 1) * C + c];
+    for (int t = 0; t < ngroups; ++t) {
+        s1 += groups[((size_t)t * 2 + 0) * C + c];
+        s2 += groups[((size_t)t * 2 + 1) * C + c];
     }
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
@@ -36,12 +52,15 @@ __global__ void bn_finalize_kernel(const float *__restrict__ partials, int tiles
     }
 }
 
-constexpr int APPLY_ROWS = 128;  // rows (pixels) per block
+static int apply_rows_per_block(int P) {  // ~2048 blocks, 128..2048 rows each (multiple of 128)
+    int r = (P / 2048 + 127) / 128 * 128;
+    return r < 128 ? 128 : (r > 2048 ? 2048 : r);
+}
 
 struct ApplyArgs {
     const float *y, *scale, *shift, *alpha, *res, *res_scale, *res_shift, *mask;
     float *out, *stats;
-    int P, Ho, Wo, C, res_stride, Hr, Wr;
+    int P, Ho, Wo, C, res_stride, Hr, Wr, rows_per_block;
 };
 
 // Threads are laid out [rows_per_pass][C/4]; each thread keeps its 4 channels for the whole block
@@ -62,9 +81,9 @@ __global__ __launch_bounds__(256) void bn_apply_nhwc_kernel(ApplyArgs p) {
         rt = *reinterpret_cast<const float4 *>(p.res_shift + c);
     }
     float s1[4] = {0, 0, 0, 0}, s2[4] = {0, 0, 0, 0};
-    const int row0 = blockIdx.x * APPLY_ROWS;
+    const int row0 = blockIdx.x * p.rows_per_block;
     if (active) {
-        for (int r = row0 + tr; r < min(p.P, row0 + APPLY_ROWS); r += rpp) {
+        for (int r = row0 + tr; r < min(p.P, row0 + p.rows_per_block); r += rpp) {
             const size_t off = (size_t)r * p.C + c;
             float4 v = *reinterpret_cast<const float4 *>(p.y + off);
             float o[4] = {v.x * sc.x + sh.x, v.y * sc.y + sh.y, v.z * sc.z + sh.z, v.w * sc.w + sh.w};
@@ -121,19 +140,36 @@ __global__ __launch_bounds__(256) void bn_apply_nhwc_kernel(ApplyArgs p) {
 
 using namespace cer;
 
+extern "C" size_t cer_bn_finalize_workspace_bytes(int tiles, int C) {
+    if (tiles <= 0 || C <= 0) return 0;
+    const int groups = tiles < FIN_MAX_GROUPS ? tiles : FIN_MAX_GROUPS;
+    return (size_t)groups * 2 * C * sizeof(double);
+}
+
 extern "C" int cer_bn_finalize(const float *partials, int tiles, int C, double count, const float *gamma,
                                const float *beta, float *running_mean, float *running_var, float momentum, float eps,
-                               float *scale, float *shift, void *stream) {
+                               float *scale, float *shift, void *workspace, size_t workspace_bytes, void *stream) {
     if (!partials || tiles <= 0 || C <= 0 || !(count > 0) || !gamma || !beta || !scale || !shift ||
         ((running_mean == nullptr) != (running_var == nullptr)))
         return cer_set_error(CER_ERR_INVALID_ARG, "bn_finalize: bad argument");
-    CER_LAUNCH(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, partials, tiles, C, count,
-               gamma, beta, running_mean, running_var, momentum, eps, scale, shift);
+    if (!workspace || workspace_bytes < cer_bn_finalize_workspace_bytes(tiles, C) || ((uintptr_t)workspace & 7))
+        return cer_set_error(CER_ERR_WORKSPACE, "bn_finalize: workspace too small or not 8-byte aligned");
+    const int groups = tiles < FIN_MAX_GROUPS ? tiles : FIN_MAX_GROUPS;
+    const int rows_per_group = (tiles + groups - 1) / groups;
+    const int used = (tiles + rows_per_group - 1) / rows_per_group;
+    CER_LAUNCH(bn_partial_reduce_kernel, dim3(used), dim3(256), 0, (hipStream_t)stream, partials, tiles, C,
+               rows_per_group, (double *)workspace);
+    CER_LAUNCH(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const double *)workspace,
+               used, C, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }
 
-extern "C" int cer_bn_apply_stats_tiles(int P) { return P > 0 ? (P + APPLY_ROWS - 1) / APPLY_ROWS : 0; }
+extern "C" int cer_bn_apply_stats_tiles(int P) {
+    if (P <= 0) return 0;
+    const int r = apply_rows_per_block(P);
+    return (P + r - 1) / r;
+}
 
 extern "C" int cer_bn_apply_nhwc(const float *y, const float *scale, const float *shift, const float *alpha,
                                  const float *res, const float *res_scale, const float *res_shift, const float *mask,
@@ -148,7 +184,7 @@ extern "C" int cer_bn_apply_nhwc(const float *y, const float *scale, const float
     if (res && (res_stride <= 0 || (Ho - 1) * res_stride >= Hr || (Wo - 1) * res_stride >= Wr))
         return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc: residual geometry out of range");
     ApplyArgs a{y, scale, shift, alpha, res, res_scale, res_shift, mask, out, stats,
-                N * Ho * Wo, Ho, Wo, C, res_stride, Hr, Wr};
+                N * Ho * Wo, Ho, Wo, C, res_stride, Hr, Wr, apply_rows_per_block(N * Ho * Wo)};
     CER_LAUNCH(bn_apply_nhwc_kernel, dim3(cer_bn_apply_stats_tiles(a.P)), dim3(256), 0, (hipStream_t)stream, a);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;

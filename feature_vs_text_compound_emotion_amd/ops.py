@@ -148,9 +148,12 @@ def bn_finalize(partials, count, gamma, beta, running_mean=None, running_var=Non
     _dev_f32(partials, "partials")
     tiles, _, c = partials.shape
     scale, shift = _empty((c,), partials), _empty((c,), partials)
-    check(_lib.load().cer_bn_finalize(ptr(partials), tiles, c, float(count), ptr(gamma), ptr(beta),
-                                      ptr(running_mean), ptr(running_var), momentum, eps, ptr(scale), ptr(shift),
-                                      current_stream()), "cer_bn_finalize")
+    lib = _lib.load()
+    nbytes = lib.cer_bn_finalize_workspace_bytes(tiles, c)
+    ws = torch.empty((nbytes // 8,), device=partials.device, dtype=torch.float64)
+    check(lib.cer_bn_finalize(ptr(partials), tiles, c, float(count), ptr(gamma), ptr(beta), ptr(running_mean),
+                              ptr(running_var), momentum, eps, ptr(scale), ptr(shift), ptr(ws), nbytes,
+                              current_stream()), "cer_bn_finalize")
     return scale, shift
 
 

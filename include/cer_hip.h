@@ -175,9 +175,10 @@ int cer_cross_entropy(const float *logits, const float *labels, float *loss, flo
  * cer_bn_apply_nhwc: out = mask * prelu(y*scale+shift) + (res*res_scale+res_shift), residual
  * sampled with res_stride like the conv epilogue; optionally emits the partial statistics of
  * `out` ([cer_bn_apply_stats_tiles(P)][2][C]) for the next BatchNorm. */
+size_t cer_bn_finalize_workspace_bytes(int tiles, int C);
 int cer_bn_finalize(const float *partials, int tiles, int C, double count, const float *gamma, const float *beta,
                     float *running_mean, float *running_var, float momentum, float eps,
-                    float *scale, float *shift, void *stream);
+                    float *scale, float *shift, void *workspace, size_t workspace_bytes, void *stream);
 int cer_bn_apply_stats_tiles(int P);
 int cer_bn_apply_nhwc(const float *y, const float *scale, const float *shift, const float *alpha,
                       const float *res, const float *res_scale, const float *res_shift, const float *mask,

@@ -37,8 +37,7 @@ def test_invalid_arguments_report_errors_without_a_gpu():
     rc = lib.cer_l2norm_rows(None, None, 0, 0, None)
     assert rc == -1 and b"l2norm_rows" in lib.cer_last_error()
     d = _lib.ConvDesc()
-    assert lib.cer_conv2d_fwd(ctypes.byref(d), None, None, None, None, None, None, None, None, None, None, None, 0,
-                              None) == -1
+    assert lib.cer_conv2d_fwd(ctypes.byref(d), *([None] * 12), 0, None) == -1
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):
