@@ -347,3 +347,68 @@ def copy_cols(x, out):
     _, _, y_ld = _rows(out, "out")
     check(_lib.load().cer_copy_cols(ptr(x), x_ld, ptr(out), y_ld, r, c, current_stream()), "cer_copy_cols")
     return out
+
+
+# ------------------------------------------------------------------ audio / text encoders
+def logmel(pcm_int16, pad_samples, mel_matrix_f64, log_offset=0.01):
+    """pcm [clips, S] int16 (16 kHz) -> log-mel [clips, frames, 64] float32."""
+    if not (pcm_int16.is_cuda and pcm_int16.dtype == torch.int16 and pcm_int16.is_contiguous() and pcm_int16.dim() == 2):
+        raise ValueError("pcm: expected a contiguous [clips, samples] int16 GPU tensor")
+    if not (mel_matrix_f64.is_cuda and mel_matrix_f64.dtype == torch.float64 and tuple(mel_matrix_f64.shape) == (257, 64)
+            and mel_matrix_f64.is_contiguous()):
+        raise ValueError("mel matrix: expected a contiguous [257, 64] float64 GPU tensor")
+    lib = _lib.load()
+    clips, n = pcm_int16.shape
+    frames = lib.cer_logmel_num_frames(n, pad_samples)
+    out = torch.empty((clips, frames, 64), device=pcm_int16.device, dtype=torch.float32)
+    check(lib.cer_logmel_fwd(ptr(pcm_int16), clips, n, pad_samples, ptr(mel_matrix_f64), log_offset, ptr(out),
+                             current_stream()), "cer_logmel_fwd")
+    return out
+
+
+def frame_examples(logmel_t, starts_i32, win=96):
+    """[clips, frames, 64] -> [clips, n_examples, win, 64] at the given start rows."""
+    _dev_f32(logmel_t, "logmel")
+    if not (starts_i32.is_cuda and starts_i32.dtype == torch.int32 and starts_i32.is_contiguous()):
+        raise ValueError("starts: expected a contiguous int32 GPU tensor")
+    clips, frames, _ = logmel_t.shape
+    n = starts_i32.numel()
+    out = torch.empty((clips, n, win, 64), device=logmel_t.device, dtype=torch.float32)
+    check(_lib.load().cer_frame_examples(ptr(logmel_t), ptr(starts_i32), ptr(out), clips, frames, n, win,
+                                         current_stream()), "cer_frame_examples")
+    return out
+
+
+def bert_embed_ln(ids, word, pos, typ, gamma, beta, eps=1e-12):
+    if not (ids.is_cuda and ids.dtype == torch.int64 and ids.is_contiguous() and ids.dim() == 2):
+        raise ValueError("ids: expected a contiguous [B, S] int64 GPU tensor")
+    for t, n in ((word, "word"), (pos, "pos"), (typ, "type"), (gamma, "gamma"), (beta, "beta")):
+        _dev_f32(t, n)
+    b, s = ids.shape
+    hd = word.shape[1]
+    y = torch.empty((b, s, hd), device=ids.device, dtype=torch.float32)
+    check(_lib.load().cer_bert_embed_ln(ptr(ids), ptr(word), ptr(pos), ptr(typ), ptr(gamma), ptr(beta), ptr(y), b, s, hd,
+                                        word.shape[0], pos.shape[0], eps, current_stream()), "cer_bert_embed_ln")
+    return y
+
+
+def attention(q, k, v, out, batch, heads, sq, sk, d, q_strides, k_strides, v_strides, o_strides, scale, key_mask=None):
+    """Strided attention: element (b, s, h, :) at base + b*st[0] + s*st[1] + h*st[2].  q/k/v/out are
+    (views into) float32 GPU buffers; only their data pointers are used."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
+        if not (t.is_cuda and t.dtype == torch.float32):
+            raise ValueError(f"{n}: expected a float32 GPU tensor")
+    if key_mask is not None and not (key_mask.is_cuda and key_mask.dtype == torch.int32 and key_mask.is_contiguous()):
+        raise ValueError("key_mask: expected a contiguous int32 GPU tensor [B, Sk]")
+    LL3 = ctypes.c_longlong * 3
+    check(_lib.load().cer_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(key_mask), ptr(out), batch, heads, sq, sk, d,
+                                        LL3(*q_strides), LL3(*k_strides), LL3(*v_strides), LL3(*o_strides), scale,
+                                        current_stream()), "cer_attention_fwd")
+    return out
+
+
+def add_inplace(y, x):
+    _dev_f32(y, "y")
+    _dev_f32(x, "x")
+    check(_lib.load().cer_add_inplace(ptr(y), ptr(x), y.numel(), current_stream()), "cer_add_inplace")
+    return y

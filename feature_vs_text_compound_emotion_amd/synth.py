@@ -109,6 +109,71 @@ def lfan_spec(modalities, n_cls=7, head_hw=5, kernel_size=5, modal_dim=32):
     return s, alias
 
 
+VGGISH_CONVS = ((0, 1, 64), (3, 64, 128), (6, 128, 256), (8, 256, 256), (11, 256, 512), (13, 512, 512))
+
+
+def vggish_spec(prefix=""):
+    """VGG/VGGish keys (models/backbone.py:16-66): features.N conv + bias, embeddings.{0,2,4}."""
+    s = OrderedDict()
+    for idx, cin, cout in VGGISH_CONVS:
+        s[f"{prefix}features.{idx}.weight"] = ((cout, cin, 3, 3), "conv_relu")
+        s[f"{prefix}features.{idx}.bias"] = ((cout,), "bias")
+    for idx, cin, cout in ((0, 512 * 4 * 6, 4096), (2, 4096, 4096), (4, 4096, 128)):
+        s[f"{prefix}embeddings.{idx}.weight"] = ((cout, cin), "linear_relu")
+        s[f"{prefix}embeddings.{idx}.bias"] = ((cout,), "bias")
+    return s
+
+
+def bert_spec(prefix="", layers=12, hidden=768, inter=3072, vocab=30522, max_pos=512, pooler=True):
+    """HF BertModel keys for a bert-base-shaped encoder (local BertConfig(), 199 entries)."""
+    s = OrderedDict()
+    e = prefix + "embeddings."
+    s[e + "word_embeddings.weight"] = ((vocab, hidden), "bert_w")
+    s[e + "position_embeddings.weight"] = ((max_pos, hidden), "bert_w")
+    s[e + "token_type_embeddings.weight"] = ((2, hidden), "bert_w")
+    s[e + "LayerNorm.weight"] = ((hidden,), "bn_w")
+    s[e + "LayerNorm.bias"] = ((hidden,), "bias")
+    for i in range(layers):
+        L = f"{prefix}encoder.layer.{i}."
+        for name, (o, n) in (("attention.self.query", (hidden, hidden)), ("attention.self.key", (hidden, hidden)),
+                             ("attention.self.value", (hidden, hidden)), ("attention.output.dense", (hidden, hidden))):
+            s[L + name + ".weight"] = ((o, n), "bert_lin")
+            s[L + name + ".bias"] = ((o,), "bias")
+        s[L + "attention.output.LayerNorm.weight"] = ((hidden,), "bn_w")
+        s[L + "attention.output.LayerNorm.bias"] = ((hidden,), "bias")
+        s[L + "intermediate.dense.weight"] = ((inter, hidden), "bert_lin")
+        s[L + "intermediate.dense.bias"] = ((inter,), "bias")
+        s[L + "output.dense.weight"] = ((hidden, inter), "bert_lin")
+        s[L + "output.dense.bias"] = ((hidden,), "bias")
+        s[L + "output.LayerNorm.weight"] = ((hidden,), "bn_w")
+        s[L + "output.LayerNorm.bias"] = ((hidden,), "bias")
+    if pooler:
+        s[prefix + "pooler.dense.weight"] = ((hidden, hidden), "bert_lin")
+        s[prefix + "pooler.dense.bias"] = ((hidden,), "bias")
+    return s
+
+
+def make_audio_int16(seconds=1.0, sample_rate=16000, seed=4321):
+    """int16 PCM, round(3000*N(0,1)) clipped."""
+    g = torch.Generator().manual_seed(seed)
+    n = int(round(seconds * sample_rate))
+    return torch.clamp(torch.round(torch.randn(n, generator=g) * 3000.0), -32768, 32767).to(torch.int16)
+
+
+def make_token_ids(batch, length, seed=777, pad_from=None):
+    """[CLS]=101, U{1000..30521}, [SEP]=102; optional zero padding from ``pad_from``."""
+    g = torch.Generator().manual_seed(seed)
+    ids = torch.randint(1000, 30522, (batch, length), generator=g)
+    mask = torch.ones(batch, length, dtype=torch.long)
+    ids[:, 0] = 101
+    for b in range(batch):
+        end = length if pad_from is None else pad_from[b]
+        ids[b, end - 1] = 102
+        ids[b, end:] = 0
+        mask[b, end:] = 0
+    return ids, mask
+
+
 def _draw(shape, kind, g):
     if kind == "count":
         return torch.zeros((), dtype=torch.long)
@@ -117,6 +182,17 @@ def _draw(shape, kind, g):
         for d in shape[1:]:
             fan_in *= d
         return torch.randn(shape, generator=g) * (1.0 / fan_in) ** 0.5
+    if kind == "conv_relu":  # He init keeps ReLU stacks (VGGish) at O(1)
+        fan_in = 1
+        for d in shape[1:]:
+            fan_in *= d
+        return torch.randn(shape, generator=g) * (2.0 / fan_in) ** 0.5
+    if kind == "linear_relu":
+        return torch.randn(shape, generator=g) * (2.0 / shape[1]) ** 0.5
+    if kind == "bert_w":
+        return torch.randn(shape, generator=g) * 0.05
+    if kind == "bert_lin":
+        return torch.randn(shape, generator=g) * (1.0 / shape[1]) ** 0.5
     if kind == "linear":
         bound = (1.0 / shape[1]) ** 0.5
         return (torch.rand(shape, generator=g) * 2 - 1) * bound

@@ -185,6 +185,40 @@ int cer_bn_apply_nhwc(const float *y, const float *scale, const float *shift, co
                       float *out, float *stats, int N, int Ho, int Wo, int C, int res_stride, int Hr, int Wr,
                       void *stream);
 
+/* ------------------------------------------------------------------------
+ * Audio / text encoder front ends and attention.
+ * ---------------------------------------------------------------------- */
+
+/* VGGish log-mel front end (reference abaw5_pre_processing/base/vggish/mel_features.py:75-114,
+ * 207-236; vggish_input.py:84-98): pcm [clips][num_samples] int16 at 16 kHz -> /32768 -> `pad_samples`
+ * of edge padding -> periodic-Hann 400/160 frames -> |DFT 512| -> mel_matrix [257][64] (float64,
+ * host-computed constant) -> log(x + log_offset).  logmel [clips][cer_logmel_num_frames()][64] fp32;
+ * the DFT and mel product run in float64 like the reference's numpy. */
+int cer_logmel_num_frames(int num_samples, int pad_samples);
+int cer_logmel_fwd(const int16_t *pcm, int clips, int num_samples, int pad_samples, const double *mel_matrix,
+                   float log_offset, float *logmel, void *stream);
+/* examples[c][e][f][:] = logmel[c][starts[e]+f][:] (my_frame, mel_features.py:21-49; the caller
+ * computes `starts` with the reference's round-half-to-even rule). */
+int cer_frame_examples(const float *logmel, const int *starts, float *examples, int clips, int frames_per_clip,
+                       int n_examples, int win, void *stream);
+
+/* BERT embeddings: y[b][s] = LayerNorm(word[ids[b][s]] + pos[s] + type[0]) (transformers
+ * BertEmbeddings; reference call site abaw5_pre_processing/base/speech.py:603-606). ids int64. */
+int cer_bert_embed_ln(const long long *ids, const float *word, const float *pos, const float *type,
+                      const float *gamma, const float *beta, float *y, int B, int S, int Hd, int vocab,
+                      int max_pos, float eps, void *stream);
+
+/* out = softmax(q k^T * scale + key mask) v on the fp32 matrix cores (flash style, exact fp32).
+ * Element (b, s, h, d) of a tensor sits at ptr + b*strides[0] + s*strides[1] + h*strides[2] + d.
+ * key_mask [B][Sk] (1 = attend) or NULL.  D in {32, 64, 128}.  Replaces BertSelfAttention and the
+ * nn.MultiheadAttention of the JMT/MT heads (reference models/model.py:716-750, 967-972). */
+int cer_attention_fwd(const float *q, const float *k, const float *v, const int *key_mask, float *out,
+                      int B, int H, int Sq, int Sk, int D, const long long *q_strides, const long long *k_strides,
+                      const long long *v_strides, const long long *o_strides, float scale, void *stream);
+
+/* y += x */
+int cer_add_inplace(float *y, const float *x, size_t n, void *stream);
+
 /* Pre-scaled dropout keep-mask, a pure function of (seed, offset + i). */
 int cer_dropout_mask(float *mask, size_t n, float p, uint64_t seed, uint64_t offset, void *stream);
 

@@ -22,3 +22,5 @@ from .ir50 import ir50_forward, ir50_block_plan, IR50_STAGES  # noqa: F401
 from .tcn import tcn_forward, weight_norm_weight  # noqa: F401
 from .fusion import lfan_fusion_forward  # noqa: F401
 from .lfan import lfan_forward, cross_entropy_mean, sgd_nesterov_step  # noqa: F401
+from .vggish import vggish_forward, waveform_to_examples, wav_int16_to_examples, log_mel_spectrogram  # noqa: F401,E402
+from .bert import bert_hidden_states, bert_token_features, exclude_padding  # noqa: F401,E402

@@ -82,3 +82,40 @@ def test_visual_backbone_alone():
         emb, feat = oracle.ir50_forward(frames, vsd, "backbone.", return_features=True)
     assert np.abs(emb.numpy() - g["emb"]).max() < TOL
     assert np.abs(feat.mean((2, 3)).numpy() - g["feat_mean"]).max() < 1e-4
+
+
+def test_logmel_front_end_matches_reference():
+    g = golden("logmel_examples.npz")
+    sr, fps, seed = [int(v) for v in g["meta"]]
+    pcm = synth.make_audio_int16(1.0, sr, seed=seed)
+    ex = oracle.wav_int16_to_examples(pcm.numpy(), sr, 0.96, 1.0 / fps)
+    assert ex.shape == (33, 96, 64)
+    assert np.abs(ex.astype(np.float32) - g["examples"]).max() == 0.0
+    assert np.abs(oracle.log_mel_spectrogram(np.pad(pcm.numpy() / 32768.0, (0, sr), "edge")) - g["log_mel"]).max() < 1e-12
+    from oracle.vggish import example_starts
+    assert example_starts(198, 96, 2.5) == list(g["starts_hop25"])  # round-half-to-even: 0, 2, 5, 8, 10 ...
+
+
+def test_vggish_matches_reference():
+    g = golden("vggish_eval.npz")
+    n, wseed = [int(v) for v in g["meta"]]
+    vsd = synth.make_state_dict(synth.vggish_spec(""), seed=wseed)
+    x = golden("logmel_examples.npz")["examples"][:n]
+    with torch.no_grad():
+        emb = oracle.vggish_forward(x, vsd)
+    assert np.abs(emb.numpy() - g["emb"]).max() < 1e-4
+
+
+def test_bert_features_match_transformers():
+    g = golden("bert_eval.npz")
+    wseed, s1, s2 = [int(v) for v in g["meta"]]
+    bsd = synth.make_state_dict(synth.bert_spec(""), seed=wseed)
+    ids, mask = synth.make_token_ids(3, 24, seed=s1, pad_from=[24, 17, 9])
+    with torch.no_grad():
+        tok = oracle.bert_token_features(ids, mask, bsd)
+    assert np.array_equal(mask.numpy(), g["mask"])
+    assert np.abs(tok.numpy()[:, :, ::8] - g["tok_sum"])[mask.bool().numpy()].max() < 2e-4
+    ids2, mask2 = synth.make_token_ids(2, 24, seed=s2, pad_from=[20, 12])
+    with torch.no_grad():
+        feats = oracle.exclude_padding(oracle.bert_token_features(ids2, mask2, bsd), mask2)
+    assert np.abs(feats.numpy()[:, ::8] - g["feats_excl"]).max() < 2e-4
