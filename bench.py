@@ -54,19 +54,75 @@ def build_model(hw, length, device):
     return model.to(device), sd
 
 
-def cpu_baseline(hw, length):
+def host_threads():
+    """Threads for the CPU baseline.  The GPU box gives a job a CFS quota (cpu.max) far below the
+    visible CPU count; torch's default of one thread per visible CPU then gets throttled (measured on
+    the round-1 box, 16-CPU quota of a 2 x EPYC 9575F: 16 threads 0.45, 32 threads 0.54, 128 threads
+    0.18 TFLOP/s sustained on a 3x3 conv), so use twice the quota, capped by the visible CPUs."""
+    n = os.cpu_count() or 1
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, 2 * int(-(-int(quota) // int(period)))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def build_extractor(batch, rank, dev):
+    """VGGish + BERT with seeded weights and one resident raw batch: 1 s of 16 kHz PCM and a 64-slot
+    sentence (63 tokens + 1 pad: the reference's exclude_padding rejects a sentence with no pad)."""
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.audio_backbone import AudioBackbone
+    from feature_vs_text_compound_emotion_amd.feature_extractor import MultimodalFeatureExtractor
+    from feature_vs_text_compound_emotion_amd.text_encoder import BertEncoderHIP
+    ab, te = AudioBackbone(), BertEncoderHIP()
+    ab.backbone.load_state_dict(synth.make_state_dict(synth.vggish_spec(""), seed=21), strict=True)
+    te.load_state_dict(synth.make_state_dict(synth.bert_spec(""), seed=31), strict=True)
+    fx = MultimodalFeatureExtractor(ab, te, fps=32).to(dev).eval()
+    pcm = torch.stack([synth.make_audio_int16(1.0, 16000, seed=5000 + rank * 1000 + i) for i in range(batch)])
+    ids, mask = synth.make_token_ids(batch, 64, seed=900 + rank, pad_from=[63] * batch)
+    return fx, {"pcm": pcm.to(dev), "ids": ids.to(dev), "mask": mask.to(dev), "mask_cpu": mask}
+
+
+def cpu_baseline(hw, length, encoders=True):
     """CPU oracle, same step, bounded sample (about 10-30 s)."""
     from feature_vs_text_compound_emotion_amd import synth
     from oracle.lfan import cross_entropy_mean, lfan_forward, sgd_nesterov_step
-    threads = torch.get_num_threads()
+    threads = host_threads()
+    torch.set_num_threads(threads)
     sd = synth.lfan_state_dict(MODS, n_cls=7, head_hw=hw // 8, seed=0)
     alias = synth.lfan_spec(MODS, head_hw=hw // 8)[1]
     names = [k for k in sd if not k.startswith("spatial.") and k not in alias
              and not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
-    clips, steps = (4, 3) if hw <= 64 else (1, 1)
+    clips, steps = (4, 1) if hw <= 64 else (1, 1)
 
-    def step(b, l, h, sdx):
+    if encoders:
+        import oracle
+        from feature_vs_text_compound_emotion_amd.feature_extractor import align_tokens_to_frames
+        vsd = synth.make_state_dict(synth.vggish_spec(""), seed=21)
+        bsd = synth.make_state_dict(synth.bert_spec(""), seed=31)
+
+    def encode(xs, b, l):
+        """oracle VGGish + BERT on raw audio / token ids (same work as the GPU step)."""
+        aud, txt = [], []
+        ids, mask = synth.make_token_ids(b, 64, seed=900, pad_from=[63] * b)
+        with torch.no_grad():
+            tok = oracle.bert_token_features(ids, mask, bsd)
+            for i in range(b):
+                ex = oracle.wav_int16_to_examples(synth.make_audio_int16(1.0, 16000, seed=5000 + i).numpy(), 16000, 0.96,
+                                                  1.0 / 32)[:l]
+                aud.append(oracle.vggish_forward(ex.astype("float32"), vsd))
+                words = oracle.exclude_padding(tok[i:i + 1], mask[i:i + 1])
+                txt.append(words[torch.tensor(align_tokens_to_frames(words.shape[0], l))])
+        xs["vggish"] = torch.stack(aud).unsqueeze(1)
+        xs["bert"] = torch.stack(txt).unsqueeze(1)
+        return xs
+
+    def step(b, l, h, sdx, enc=False):
         xs, ls = synth.make_clip_batch(MODS, b, l, hw=h, seed=7)
+        if enc:
+            xs = encode(xs, b, l)
         params = [sdx[n].clone().requires_grad_(True) for n in names]
         s = dict(sdx)
         s.update(zip(names, params))
@@ -81,11 +137,12 @@ def cpu_baseline(hw, length):
     step(1, length, 40, warm_sd)  # thread-pool / allocator warm-up, untimed
     t0 = time.perf_counter()
     for _ in range(steps):
-        step(clips, length, hw, sd)
+        step(clips, length, hw, sd, enc=encoders)
     dt = time.perf_counter() - t0
     return {"value": clips * steps / dt, "unit": "clips/s", "cores": threads, "kind": "port",
-            "sample": f"{steps} train step(s) of {clips} clip(s) x {length} frames x {hw}x{hw} (tri-modal LFAN, "
-                      f"oracle on torch-CPU fp32, {threads} threads), {dt:.1f} s"}
+            "sample": f"{steps} train step(s) of {clips} clip(s) x {length} frames x {hw}x{hw} (tri-modal LFAN"
+                      f"{' incl. VGGish + BERT encoders' if encoders else ''}, oracle on torch-CPU fp32, "
+                      f"{threads} threads), {dt:.1f} s"}
 
 
 def main():
@@ -97,6 +154,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--length", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--encoders", choices=["on", "off"], default="on",
+                    help="on: VGGish (log-mel from 1 s PCM) and BERT (64 tokens) run on the GPU inside the step; "
+                         "off: pre-computed per-frame features, as the reference trainer feeds them")
     a = ap.parse_args()
 
     from feature_vs_text_compound_emotion_amd import synth
@@ -118,6 +178,9 @@ def main():
     x, labels = synth.make_clip_batch(MODS, a.batch, a.length, hw=a.hw, seed=1234 + rank)
     x = {k: v.to(dev) for k, v in x.items()}
     labels = labels.to(dev)
+    fx = None
+    if a.encoders == "on":
+        fx, raw = build_extractor(a.batch, rank, dev)
 
     ev = []
 
@@ -136,7 +199,10 @@ def main():
 
     def step():
         ddp.zero_grad()
-        out = model(x)
+        inputs = x
+        if fx is not None:  # raw audio + token ids -> per-frame features on the GPU (frozen encoders)
+            inputs = fx(x["video"], raw["pcm"], raw["ids"], raw["mask"], raw["mask_cpu"])
+        out = model(inputs)
         loss = cross_entropy_loss(out, labels)
         loss.backward()
         ddp.all_reduce_gradients()
@@ -178,7 +244,10 @@ def main():
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"LFAN tri-modal training step: frozen IR-50 forward on {a.batch}x{a.length} frames "
                                    f"of {a.hw}x{a.hw} + TCN/fusion/regressor forward+backward + CE + Nesterov SGD; "
-                                   "vggish/bert as pre-computed per-frame features (as the reference trainer feeds them)",
+                                   + ("VGGish (log-mel of 1 s PCM, 32 examples/clip) and BERT-base (64-token sentence) run on "
+                                      "the GPU inside the step" if a.encoders == "on" else
+                                      "vggish/bert as pre-computed per-frame features (as the reference trainer feeds them)"),
+                       "encoders_on_gpu": a.encoders == "on",
                        "clips_per_gpu": a.batch, "global_batch": a.batch * world, "frames_per_clip": a.length,
                        "frame_hw": a.hw, "n_classes": 7, "parallelism": f"dp{world} over clips, flat-bucket RCCL all-reduce",
                        "loss": float(loss.item())},
@@ -189,7 +258,7 @@ def main():
                          "algorithmic_flops_per_step": flops, "ms_per_step_in_kernel": enc_ms},
         }
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(a.hw, a.length)
+            res["cpu_baseline"] = cpu_baseline(a.hw, a.length, a.encoders == "on")
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.barrier()

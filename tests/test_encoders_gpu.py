@@ -106,3 +106,41 @@ def test_bert_features_match_transformers_fixture_and_oracle():
     full, fmask = synth.make_token_ids(1, 8, seed=3)
     with pytest.raises(ValueError):
         enc.exclude_padding(enc(full, fmask), fmask)
+
+
+def test_token_to_frame_alignment_rule():
+    from feature_vs_text_compound_emotion_amd.feature_extractor import align_tokens_to_frames
+    assert align_tokens_to_frames(3, 8) == [0, 0, 0, 1, 1, 1, 2, 2]      # more_itertools.divide(3, range(8))
+    assert align_tokens_to_frames(5, 3) == [0, 1, 2]                     # extra words are dropped
+    assert align_tokens_to_frames(0, 4) == []
+    assert align_tokens_to_frames(62, 32) == list(range(32))
+
+
+def test_feature_extractor_matches_oracle_composition():
+    import oracle
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.audio_backbone import AudioBackbone
+    from feature_vs_text_compound_emotion_amd.feature_extractor import MultimodalFeatureExtractor, align_tokens_to_frames
+    from feature_vs_text_compound_emotion_amd.text_encoder import BertEncoderHIP
+    vsd = synth.make_state_dict(synth.vggish_spec(""), seed=41)
+    bsd = synth.make_state_dict(synth.bert_spec("", layers=4), seed=42)
+    ab = AudioBackbone()
+    ab.backbone.load_state_dict(vsd)
+    te = BertEncoderHIP(num_hidden_layers=4)
+    te.load_state_dict(bsd)
+    fx = MultimodalFeatureExtractor(ab, te, fps=8).cuda().eval()
+    length = 12
+    pcm = torch.stack([synth.make_audio_int16(1.0, 16000, seed=s) for s in (7, 8)])
+    ids, mask = synth.make_token_ids(2, 10, seed=9, pad_from=[9, 6])
+    frames = torch.zeros(2, length, 3, 40, 40)
+    out = fx(frames.cuda(), pcm.cuda(), ids.cuda(), mask.cuda())
+    assert tuple(out["vggish"].shape) == (2, 1, length, 128) and tuple(out["bert"].shape) == (2, 1, length, 768)
+    for b in range(2):
+        ex = oracle.wav_int16_to_examples(pcm[b].numpy(), 16000, 0.96, 1.0 / 8)   # 9 examples < 12 frames
+        emb = oracle.vggish_forward(ex.astype("float32"), vsd)
+        emb = torch.cat([emb, emb[-1:].expand(length - emb.shape[0], 128)])
+        assert (out["vggish"][b, 0].cpu() - emb).abs().max().item() < 1e-4 * max(1.0, emb.abs().max().item())
+        words = oracle.exclude_padding(oracle.bert_token_features(ids[b:b + 1], mask[b:b + 1], bsd, num_layers=4),
+                                       mask[b:b + 1])
+        ref = words[torch.tensor(align_tokens_to_frames(words.shape[0], length))]
+        assert (out["bert"][b, 0].cpu() - ref).abs().max().item() < 2e-4
