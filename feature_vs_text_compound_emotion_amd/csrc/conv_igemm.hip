@@ -117,18 +117,25 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c,
 
 // VAR bit 0: s_setprio(1) around the MFMA cluster; bit 1: single LDS buffer (two barriers per
 // step, half the LDS -> more resident blocks per CU).
-template <int BM, int BN, int WP, int WC, bool VEC, int VAR>
-__global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
-    constexpr bool PRIO = (VAR & 1) != 0, SINGLE = (VAR & 2) != 0;
+template <int BM, int BN, int WP, int WC, bool VEC, int VAR, int BKT>
+__global__ __launch_bounds__(WP * WC * 64, 3) void conv_igemm_kernel(ConvArgs p) {
+    constexpr int NT = WP * WC * 64;   // threads per block (1 or 4 waves)
+    constexpr int CH = BKT / 4;        // 16-byte chunks per staged row
+    constexpr int RPP = NT / CH;       // rows staged per pass
+    constexpr int PIT = BKT + 4;       // LDS row pitch (floats): conflict-free ds_read_b128
+    constexpr int NG = BKT / 8;        // 8-wide reduction groups per step
+    constexpr bool PRIO = (VAR & 1) != 0, SINGLE = (VAR & 2) != 0, BLKPRIO = (VAR & 4) != 0;
+    // timing-only ablations (WRONG results by construction, never selected by the picker):
+    constexpr bool ABL_NOSTAGE = (VAR & 8) != 0;   // no global loads / LDS stores inside the K loop
+    constexpr bool ABL_NOBAR = (VAR & 16) != 0;    // ... and no barriers either
     constexpr int NBUF = SINGLE ? 1 : 2;
-    static_assert(WP * WC == 4, "4 waves per block");
     constexpr int TP = BM / (32 * WP);  // 32-pixel MFMA tiles per wave
     constexpr int TC = BN / (32 * WC);  // 32-cout MFMA tiles per wave
-    constexpr int XR = BM / 32;         // activation rows staged per thread
-    constexpr int WR = BN / 32;         // weight rows staged per thread
+    constexpr int XR = BM / RPP;        // activation rows staged per thread
+    constexpr int WR = BN / RPP;        // weight rows staged per thread
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *Xs = smem;                         // [NBUF][BM][PITCH]
-    float *Ws = smem + NBUF * BM * PITCH;     // [NBUF][BN][PITCH]
+    float *Xs = smem;                         // [NBUF][BM][PIT]
+    float *Ws = smem + NBUF * BM * PIT;     // [NBUF][BN][PIT]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -150,13 +157,13 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
     const int s_begin = split * p.steps_per_split;
     const int s_end = min(p.steps, s_begin + p.steps_per_split);
 
-    // ---- staging assignment: thread -> (row srow+32*i, 16-byte chunk) ----
-    const int chunk = tid & 7, srow = tid >> 3;
+    // ---- staging assignment: thread -> (row srow+RPP*i, 16-byte chunk) ----
+    const int chunk = tid % CH, srow = tid / CH;
     int x_pix[XR], x_hi0[XR], x_wi0[XR];
     bool x_ok[XR];
 #pragma unroll
     for (int i = 0; i < XR; ++i) {
-        int m = m0 + srow + 32 * i;
+        int m = m0 + srow + RPP * i;
         x_ok[i] = m < p.M;
         int mm = x_ok[i] ? m : 0;
         int hw = p.Ho * p.Wo;
@@ -165,6 +172,42 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
         x_pix[i] = n;  // image index; pixel offset formed per tap
         x_hi0[i] = ho * p.stride - p.pad_t;
         x_wi0[i] = wo * p.stride - p.pad_l;
+    }
+    // Fast addressing (VEC path): every load is  scalar_base(step) + 32-bit per-thread offset.
+    //   x: byte offset of the row's (kh = kw = 0) tap relative to the tile's first row, and a bit
+    //      mask of the taps that fall inside the image (zero padding) -> no per-step address math;
+    //   w: row offset inside the [Cout][Kpad] panel.
+    unsigned x_rel[XR], x_taps[XR], w_rel[WR];
+    bool w_ok[WR];
+    long long tile_base = 0;  // bytes from p.x to the first row's (0,0) tap (may be negative: padding)
+    if constexpr (VEC) {
+        {
+            const int hw = p.Ho * p.Wo;
+            const int mm = m0 < p.M ? m0 : 0;
+            const int n = mm / hw, r = mm - n * hw;
+            const int ho = r / p.Wo, wo = r - ho * p.Wo;
+            tile_base = ((long long)(n * p.H + ho * p.stride - p.pad_t) * p.W + (wo * p.stride - p.pad_l)) * p.x_ld * 4;
+        }
+#pragma unroll
+        for (int i = 0; i < XR; ++i) {
+            const long long rb = ((long long)(x_pix[i] * p.H + x_hi0[i]) * p.W + x_wi0[i]) * p.x_ld * 4;
+            x_rel[i] = x_ok[i] ? (unsigned)(rb - tile_base) + chunk * 16u : 0u;
+            unsigned bits = 0;
+            if (x_ok[i]) {
+                for (int t = 0; t < p.KH * p.KW; ++t) {
+                    const int kh = t / p.KW, kw = t - kh * p.KW;
+                    const int hi = x_hi0[i] + kh * p.dil_h, wi = x_wi0[i] + kw * p.dil_w;
+                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) bits |= 1u << t;
+                }
+            }
+            x_taps[i] = bits;
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < WR; ++i) {
+        const int crow = c0 + srow + RPP * i;
+        w_ok[i] = crow < p.Cout;
+        w_rel[i] = (unsigned)(((size_t)(srow + RPP * i) * p.Kpad + chunk * 4) * 4);
     }
 
     float4 xr[XR], wr[WR];
@@ -175,16 +218,16 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
         if constexpr (VEC) {
             const int tap = s / p.cin_steps, cc = s - tap * p.cin_steps;
             const int kh = tap / p.KW, kw = tap - kh * p.KW;
-            const int dh = kh * p.dil_h, dw = kw * p.dil_w;
-            const int cbase = cc * BK + chunk * 4;
+            const int cbase = cc * BKT + chunk * 4;
+            // wave-uniform (scalar) base of this step: tile origin + tap displacement + channel chunk
+            const char *sbase = reinterpret_cast<const char *>(p.x) + tile_base +
+                                ((long long)(kh * p.dil_h * p.W + kw * p.dil_w) * p.x_ld + cc * BKT) * 4;
+            const unsigned tapbit = 1u << tap;
             xvalid = 0;
 #pragma unroll
             for (int i = 0; i < XR; ++i) {
-                int hi = x_hi0[i] + dh, wi = x_wi0[i] + dw;
-                bool ok = x_ok[i] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;
-                if (ok) {
-                    size_t off = ((size_t)(x_pix[i] * p.H + hi) * p.W + wi) * p.x_ld + cbase;
-                    xr[i] = *reinterpret_cast<const float4 *>(p.x + off);
+                if (x_taps[i] & tapbit) {
+                    xr[i] = *reinterpret_cast<const float4 *>(sbase + x_rel[i]);
                     xvalid |= 1u << i;
                 } else {
                     xr[i] = make_float4(0, 0, 0, 0);
@@ -202,7 +245,7 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
                 float e[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    int k = s * BK + chunk * 4 + j;
+                    int k = s * BKT + chunk * 4 + j;
                     float v = 0.f;
                     if (k < K && x_ok[i]) {
                         int tap = k / p.Cin, c = k - tap * p.Cin;
@@ -221,18 +264,18 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
                 xr[i] = make_float4(e[0], e[1], e[2], e[3]);
             }
         }
+        {
+            const char *wbase = reinterpret_cast<const char *>(p.w) + ((size_t)c0 * p.Kpad + (size_t)s * BKT) * 4;
 #pragma unroll
-        for (int i = 0; i < WR; ++i) {
-            int crow = c0 + srow + 32 * i;
-            if (crow < p.Cout)
-                wr[i] = *reinterpret_cast<const float4 *>(p.w + (size_t)crow * p.Kpad + s * BK + chunk * 4);
-            else
-                wr[i] = make_float4(0, 0, 0, 0);
+            for (int i = 0; i < WR; ++i) {
+                if (w_ok[i]) wr[i] = *reinterpret_cast<const float4 *>(wbase + w_rel[i]);
+                else wr[i] = make_float4(0, 0, 0, 0);
+            }
         }
     };
 
     auto store_step = [&](int buf) {
-        float *xs = Xs + buf * BM * PITCH, *ws = Ws + buf * BN * PITCH;
+        float *xs = Xs + buf * BM * PIT, *ws = Ws + buf * BN * PIT;
 #pragma unroll
         for (int i = 0; i < XR; ++i) {
             float4 v = xr[i];
@@ -242,11 +285,11 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
                     v.z = v.z * sc.z + sh.z; v.w = v.w * sc.w + sh.w;
                 }
             }
-            *reinterpret_cast<float4 *>(xs + (srow + 32 * i) * PITCH + chunk * 4) = v;
+            *reinterpret_cast<float4 *>(xs + (srow + RPP * i) * PIT + chunk * 4) = v;
         }
 #pragma unroll
         for (int i = 0; i < WR; ++i)
-            *reinterpret_cast<float4 *>(ws + (srow + 32 * i) * PITCH + chunk * 4) = wr[i];
+            *reinterpret_cast<float4 *>(ws + (srow + RPP * i) * PIT + chunk * 4) = wr[i];
     };
 
     f32x16 acc[TC][TP];
@@ -265,17 +308,27 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
 
     for (int s = s_begin; s < s_end; ++s) {
         const int buf = SINGLE ? 0 : ((s - s_begin) & 1);
-        if (s + 1 < s_end) load_step(s + 1);
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
-        const float *xs = Xs + buf * BM * PITCH + (wp * TP * 32 + l31) * PITCH + half * 4;
-        const float *ws = Ws + buf * BN * PITCH + (wc * TC * 32 + l31) * PITCH + half * 4;
+        if constexpr (!ABL_NOSTAGE) {
+            if (s + 1 < s_end) load_step(s + 1);
+        }
+        if constexpr (BLKPRIO) {
+            // same priority for the 4 waves of a block on their 4 SIMDs -> blocks advance in lockstep
+            switch ((blockIdx.x >> 3) & 3) {
+                case 0: __builtin_amdgcn_s_setprio(0); break;
+                case 1: __builtin_amdgcn_s_setprio(1); break;
+                case 2: __builtin_amdgcn_s_setprio(2); break;
+                default: __builtin_amdgcn_s_setprio(3); break;
+            }
+        } else if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
+        const float *xs = Xs + buf * BM * PIT + (wp * TP * 32 + l31) * PIT + half * 4;
+        const float *ws = Ws + buf * BN * PIT + (wc * TC * 32 + l31) * PIT + half * 4;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
+        for (int g = 0; g < NG; ++g) {
             float4 af[TC], bf[TP];
 #pragma unroll
-            for (int a = 0; a < TC; ++a) af[a] = *reinterpret_cast<const float4 *>(ws + a * 32 * PITCH + g * 8);
+            for (int a = 0; a < TC; ++a) af[a] = *reinterpret_cast<const float4 *>(ws + a * 32 * PIT + g * 8);
 #pragma unroll
-            for (int b = 0; b < TP; ++b) bf[b] = *reinterpret_cast<const float4 *>(xs + b * 32 * PITCH + g * 8);
+            for (int b = 0; b < TP; ++b) bf[b] = *reinterpret_cast<const float4 *>(xs + b * 32 * PIT + g * 8);
 #pragma unroll
             for (int a = 0; a < TC; ++a)
 #pragma unroll
@@ -286,10 +339,12 @@ __global__ __launch_bounds__(256, 2) void conv_igemm_kernel(ConvArgs p) {
                     acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a].w, bf[b].w, acc[a][b], 0, 0, 0);
                 }
         }
-        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
-        if constexpr (SINGLE) __syncthreads();  // everyone is done reading the only buffer
-        if (s + 1 < s_end) store_step(SINGLE ? 0 : (buf ^ 1));
-        __syncthreads();
+        if constexpr (PRIO && !BLKPRIO) __builtin_amdgcn_s_setprio(0);
+        if constexpr (SINGLE && !ABL_NOBAR) __syncthreads();  // everyone is done reading the only buffer
+        if constexpr (!ABL_NOSTAGE) {
+            if (s + 1 < s_end) store_step(SINGLE ? 0 : (buf ^ 1));
+        }
+        if constexpr (!ABL_NOBAR) __syncthreads();
     }
 
     // ---- epilogue: D[i = cout][j = pixel]; reg r -> cout (r&3) + 8*(r>>2) + 4*half ----
@@ -388,16 +443,16 @@ __global__ void splitk_reduce_kernel(ConvArgs p, const float *partial) {
 // ---------------------------------------------------------------- host side
 struct TileCfg { int bm, bn; };
 
-template <int BM, int BN, int WP, int WC, int VAR>
+template <int BM, int BN, int WP, int WC, int VAR, int BKT = 32>
 static int launch_cfg(const ConvArgs &a, bool vec, hipStream_t st) {
-    const size_t lds = (size_t)((VAR & 2) ? 1 : 2) * (BM + BN) * PITCH * sizeof(float);
-    dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k), block(256);
+    const size_t lds = (size_t)((VAR & 2) ? 1 : 2) * (BM + BN) * (BKT + 4) * sizeof(float);
+    dim3 grid(a.tiles_m * a.tiles_n, 1, a.split_k), block(WP * WC * 64);
     if (vec) {
-        auto k = conv_igemm_kernel<BM, BN, WP, WC, true, VAR>;
+        auto k = conv_igemm_kernel<BM, BN, WP, WC, true, VAR, BKT>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CER_LAUNCH(k, grid, block, lds, st, a);
     } else {
-        auto k = conv_igemm_kernel<BM, BN, WP, WC, false, VAR>;
+        auto k = conv_igemm_kernel<BM, BN, WP, WC, false, VAR, BKT>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CER_LAUNCH(k, grid, block, lds, st, a);
     }
@@ -406,8 +461,8 @@ static int launch_cfg(const ConvArgs &a, bool vec, hipStream_t st) {
 }
 
 // Tile shapes: 1 = 128x128 (3 blocks/CU), 2 = 128x64 (4/CU), 4 = 64x128 (4/CU), 5 = 64x64 (5/CU);
-// all single-LDS-buffer + s_setprio (VAR 3, measured +15 % over double buffering because the
-// smaller LDS footprint admits one more block per CU).  Relative per-FLOP rates are measured
+// all single-LDS-buffer (VAR 2, measured +15 % over double buffering because the smaller LDS
+// footprint admits one more block per CU; s_setprio made no difference in this structure).  Relative per-FLOP rates are measured
 // (tools/bench_conv.py); the picker minimises rounds x tile work, which matters when the grid is
 // only a few rounds deep (40x40 frames: 1600 tiles of 128x128 on 768 slots).
 struct TileInfo { int id, bm, bn, per_cu; float rate; };
@@ -437,6 +492,9 @@ static void tile_dims(int tile, int &bm, int &bn) {
         case 1: bm = 128; bn = 128; break;
         case 2: bm = 128; bn = 64; break;
         case 4: bm = 64; bn = 128; break;
+        case 7: bm = 128; bn = 128; break;
+        case 8: bm = 128; bn = 64; break;
+        case 9: bm = 64; bn = 128; break;
         default: bm = 64; bn = 64; break;
     }
 }
@@ -448,6 +506,10 @@ static int launch_shape(int shape, const ConvArgs &a, bool vec, hipStream_t st) 
         case 2: return launch_cfg<128, 64, 2, 2, VAR>(a, vec, st);
         case 4: return launch_cfg<64, 128, 1, 4, VAR>(a, vec, st);
         case 5: return launch_cfg<64, 64, 2, 2, VAR>(a, vec, st);
+        case 6: return launch_cfg<64, 64, 1, 1, VAR, 16>(a, vec, st);    // one wave per block: no block barrier
+        case 7: return launch_cfg<128, 128, 2, 2, VAR, 16>(a, vec, st);  // BK = 16
+        case 8: return launch_cfg<128, 64, 2, 2, VAR, 16>(a, vec, st);
+        case 9: return launch_cfg<64, 128, 1, 4, VAR, 16>(a, vec, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: unknown tile id");
     }
 }
@@ -520,16 +582,25 @@ extern "C" int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const floa
     a.Kpad = cer_conv_kpad(d->KH, d->KW, d->Cin);
     a.M = d->N * d->Ho * d->Wo;
     const bool vec = (d->Cin % 32) == 0;
-    a.cin_steps = vec ? d->Cin / 32 : 1;
-    a.steps = a.Kpad / BK;
+    const int tile = pick_tile(d, d->N * d->Ho * d->Wo);
+    const int bk = (tile % 10 >= 6) ? 16 : 32;
+    a.cin_steps = vec ? d->Cin / bk : 1;
+    a.steps = a.Kpad / bk;
     a.split_k = d->split_k > a.steps ? a.steps : d->split_k;
     a.steps_per_split = (a.steps + a.split_k - 1) / a.split_k;
     a.split_k = (a.steps + a.steps_per_split - 1) / a.steps_per_split;
-    const int tile = pick_tile(d, a.M);
     int bm, bn;
     tile_dims(tile % 10, bm, bn);
     a.tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = (a.Cout + bn - 1) / bn;
+    if (vec) {
+        // the staging path addresses x and w as scalar base + 32-bit per-thread byte offset
+        if (d->KH * d->KW > 32)
+            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d_fwd: more than 32 filter taps");
+        const long long span_px = (long long)bm * d->stride * d->stride + 2ll * d->H * d->W + (long long)d->W * d->stride + 2;
+        if (span_px * a.x_ld * 4 >= (1ll << 31) || (long long)bn * a.Kpad * 4 >= (1ll << 32))
+            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d_fwd: tile footprint exceeds 32-bit staging offsets");
+    }
     hipStream_t st = (hipStream_t)stream;
     ConvArgs fin = a;
     if (a.split_k > 1) {
@@ -538,12 +609,16 @@ extern "C" int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const floa
             return cer_set_error(CER_ERR_WORKSPACE, "conv2d_fwd: split-K workspace too small");
         a.y = (float *)workspace;
     }
-    // tile = shape + 10*v: v = 0 -> shipped variant (single LDS buffer + setprio); v = 1 -> double
-    // buffered; v = 2 -> double buffered + setprio (kept for A/B measurements)
+    // tile = shape + 10*v: v = 0 -> shipped variant (single LDS buffer); v = 1 -> double buffered;
+    // v = 2 -> double buffered + setprio; 3..6 -> other A/B and timing-only ablation builds
     switch (tile / 10) {
-        case 0: rc = launch_shape<3>(tile % 10, a, vec, st); break;
+        case 0: rc = launch_shape<2>(tile % 10, a, vec, st); break;
         case 1: rc = launch_shape<0>(tile % 10, a, vec, st); break;
         case 2: rc = launch_shape<1>(tile % 10, a, vec, st); break;
+        case 3: rc = launch_shape<6>(tile % 10, a, vec, st); break;   // single buffer + per-block priority
+        case 4: rc = launch_shape<2>(tile % 10, a, vec, st); break;   // single buffer, no setprio
+        case 5: rc = launch_shape<2 + 8>(tile % 10, a, vec, st); break;        // ablation: no staging in the loop
+        case 6: rc = launch_shape<2 + 8 + 16>(tile % 10, a, vec, st); break;   // ablation: no staging, no barriers
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: unknown tile variant");
     }
     if (rc) return rc;
