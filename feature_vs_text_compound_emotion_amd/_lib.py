@@ -60,7 +60,8 @@ _SIGNATURES = {
     "cer_logmel_fwd": (c_int, [_P, c_int, c_int, c_int, _P, c_float, _P, _P]),
     "cer_frame_examples": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "cer_bert_embed_ln": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
-    "cer_attention_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P]),
+    "cer_attention_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P]),
+    "cer_attention_bwd": (c_int, [_P] * 11 + [c_int] * 5 + [_P] * 8 + [c_float, _P]),
     "cer_add_inplace": (c_int, [_P, _P, c_size_t, _P]),
     "cer_l2norm_rows": (c_int, [_P, _P, c_int, c_int, _P]),
     "cer_maxpool2x2_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),

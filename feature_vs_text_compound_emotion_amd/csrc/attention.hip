@@ -25,6 +25,7 @@ struct AttnArgs {
     const float *q, *k, *v;
     const int *key_mask;  // [B][Sk] 1 = attend, or NULL
     float *out;
+    float *lse;  // optional [B][H][Sq]: log-sum-exp of the scaled, masked scores (saved for the backward)
     long long q_sb, q_ss, q_sh;  // element strides: batch, token, head (d is contiguous)
     long long k_sb, k_ss, k_sh;
     long long v_sb, v_ss, v_sh;
@@ -130,6 +131,7 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs p) {
         }
     }
     if (!qok) return;
+    if (p.lse && half == 0) p.lse[((size_t)b * p.H + h) * p.Sq + query] = l_run > 0.f ? m_run + logf(l_run) : INFINITY;
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
     float *op = p.out + b * p.o_sb + (long long)query * p.o_ss + h * p.o_sh;
 #pragma unroll
@@ -142,12 +144,176 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs p) {
         }
 }
 
+// ------------------------------------------------------------------ backward
+// One templated kernel, two roles (see the header comment for the orientation trick):
+//   DQ mode : a wave OWNS 32 queries (Q, dO in registers; LSE, Delta per lane) and streams key
+//             tiles (K, V in LDS):      dQ^T += K^T dS^T
+//   DKV mode: a wave OWNS 32 keys (K, V in registers) and streams query tiles (Q, dO in LDS; LSE,
+//             Delta per register row):  dV^T += dO^T P,  dK^T += Q^T dS
+// with S = (owner1 . streamed1) * scale, P = exp(S - LSE[query]), dP = owner2 . streamed2,
+// dS = P * (dP - Delta[query]) * scale.  Both modes recompute S/P, so no atomics are needed and the
+// result is deterministic.  Delta = rowsum(dO * O) comes from attn_delta_kernel.
+struct AttnBwdArgs {
+    const float *q, *k, *v, *dout, *lse, *delta;
+    const int *key_mask;
+    float *dq, *dk, *dv;
+    long long q_sb, q_ss, q_sh, k_sb, k_ss, k_sh, v_sb, v_ss, v_sh, o_sb, o_ss, o_sh;  // o_* = dout strides
+    long long dq_sb, dq_ss, dq_sh, dk_sb, dk_ss, dk_sh, dv_sb, dv_ss, dv_sh;
+    int B, H, Sq, Sk;
+    float scale;
+};
+
+// delta[b][h][q] = sum_d dO * O   (one wave per (b, h, q) row)
+__global__ void attn_delta_kernel(const float *__restrict__ out, const float *__restrict__ dout, float *__restrict__ delta,
+                                  long long a_sb, long long a_ss, long long a_sh, long long o_sb, long long o_ss,
+                                  long long o_sh, int B, int H, int Sq, int D) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= B * H * Sq) return;
+    const int q = row % Sq, h = (row / Sq) % H, b = row / (Sq * H);
+    const float *op = out + b * a_sb + (long long)q * a_ss + h * a_sh;
+    const float *gp = dout + b * o_sb + (long long)q * o_ss + h * o_sh;
+    float s = 0.f;
+    for (int d = lane; d < D; d += 64) s += op[d] * gp[d];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) delta[row] = s;
+}
+
+template <int D, bool DKV>
+__global__ __launch_bounds__(256, 1) void attention_bwd_kernel(AttnBwdArgs p) {
+    constexpr int KP = D + 4, NG = D / 8, NT = D / 32;
+    __shared__ __attribute__((aligned(16))) float T1[32 * KP];  // streamed tile 1 (K or Q), pitch KP
+    __shared__ __attribute__((aligned(16))) float T2[32 * KP];  // streamed tile 2 (V or dO)
+    __shared__ float sl[32], sd[32];                            // DKV: LSE / Delta of the streamed queries
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int b = blockIdx.z, h = blockIdx.y;
+    const int So = DKV ? p.Sk : p.Sq, Ss = DKV ? p.Sq : p.Sk;  // owner / streamed lengths
+    const int orow = blockIdx.x * 128 + wave * 32 + l31;
+    const bool ook = orow < So;
+    const float *o1 = DKV ? p.k + b * p.k_sb + h * p.k_sh : p.q + b * p.q_sb + h * p.q_sh;
+    const float *o2 = DKV ? p.v + b * p.v_sb + h * p.v_sh : p.dout + b * p.o_sb + h * p.o_sh;
+    const long long o1s = DKV ? p.k_ss : p.q_ss, o2s = DKV ? p.v_ss : p.o_ss;
+    const float *s1 = DKV ? p.q + b * p.q_sb + h * p.q_sh : p.k + b * p.k_sb + h * p.k_sh;
+    const float *s2 = DKV ? p.dout + b * p.o_sb + h * p.o_sh : p.v + b * p.v_sb + h * p.v_sh;
+    const long long s1s = DKV ? p.q_ss : p.k_ss, s2s = DKV ? p.o_ss : p.v_ss;
+    const float *lse = p.lse + ((size_t)b * p.H + h) * p.Sq, *delta = p.delta + ((size_t)b * p.H + h) * p.Sq;
+    const int *mbase = p.key_mask ? p.key_mask + (size_t)b * p.Sk : nullptr;
+
+    float4 r1[NG], r2[NG];  // owner fragments: lane half `half` holds d = 8g + 4*half + e
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+        r1[g] = ook ? *reinterpret_cast<const float4 *>(o1 + (long long)orow * o1s + 8 * g + 4 * half) : make_float4(0, 0, 0, 0);
+        r2[g] = ook ? *reinterpret_cast<const float4 *>(o2 + (long long)orow * o2s + 8 * g + 4 * half) : make_float4(0, 0, 0, 0);
+    }
+    float my_lse = INFINITY, my_delta = 0.f;
+    bool my_keyok = true;
+    if (!DKV) {
+        if (ook) { my_lse = lse[orow]; my_delta = delta[orow]; }
+    } else {
+        my_keyok = ook && (!mbase || mbase[orow] != 0);
+    }
+    f32x16 accA[NT], accB[DKV ? NT : 1];
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            accA[t][r] = 0.f;
+            if constexpr (DKV) accB[t][r] = 0.f;
+        }
+
+    for (int t0 = 0; t0 < Ss; t0 += 32) {
+        __syncthreads();
+        for (int i = tid; i < 32 * (D / 4); i += 256) {
+            const int row = i / (D / 4), c4 = (i - row * (D / 4)) * 4;
+            float4 a = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
+            if (t0 + row < Ss) {
+                a = *reinterpret_cast<const float4 *>(s1 + (long long)(t0 + row) * s1s + c4);
+                c = *reinterpret_cast<const float4 *>(s2 + (long long)(t0 + row) * s2s + c4);
+            }
+            *reinterpret_cast<float4 *>(&T1[row * KP + c4]) = a;
+            *reinterpret_cast<float4 *>(&T2[row * KP + c4]) = c;
+        }
+        if (DKV && tid < 32) {
+            const bool ok = t0 + tid < p.Sq;
+            sl[tid] = ok ? lse[t0 + tid] : INFINITY;
+            sd[tid] = ok ? delta[t0 + tid] : 0.f;
+        }
+        __syncthreads();
+        f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
+        const float *a1 = &T1[l31 * KP + 4 * half], *a2 = &T2[l31 * KP + 4 * half];
+#pragma unroll
+        for (int g = 0; g < NG; ++g) {
+            const float4 x = *reinterpret_cast<const float4 *>(a1 + 8 * g);
+            const float4 y = *reinterpret_cast<const float4 *>(a2 + 8 * g);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(x.x, r1[g].x, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(x.y, r1[g].y, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(x.z, r1[g].z, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x2f32(x.w, r1[g].w, s, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(y.x, r2[g].x, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(y.y, r2[g].y, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(y.z, r2[g].z, dp, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_32x32x2f32(y.w, r2[g].w, dp, 0, 0, 0);
+        }
+        // register r <-> streamed row (r&3) + 8*(r>>2) + 4*half; lane <-> owner row
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int srow = (r & 3) + 8 * (r >> 2) + 4 * half;
+            float l, dl;
+            bool ok;
+            if (DKV) {  // streamed = query, owner = key
+                l = sl[srow]; dl = sd[srow];
+                ok = my_keyok && (t0 + srow < p.Sq);
+            } else {    // streamed = key, owner = query
+                l = my_lse; dl = my_delta;
+                const int key = t0 + srow;
+                ok = ook && key < p.Sk && (!mbase || mbase[key] != 0);
+            }
+            const float pr = ok ? expf(s[r] * p.scale - l) : 0.f;
+            s[r] = pr;                                   // P
+            dp[r] = pr * (dp[r] - dl) * p.scale;         // dS (already times the score scale)
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int srow = (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+            for (int t = 0; t < NT; ++t) {
+                accA[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(T1[srow * KP + 32 * t + l31], dp[r], accA[t], 0, 0, 0);
+                if constexpr (DKV) accB[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(T2[srow * KP + 32 * t + l31], s[r], accB[t], 0, 0, 0);
+            }
+        }
+    }
+    if (!ook) return;
+    // accA = (DQ: dQ^T | DKV: dK^T), accB = dV^T; layout [d][owner row]
+    float *oa = DKV ? p.dk + b * p.dk_sb + (long long)orow * p.dk_ss + h * p.dk_sh
+                    : p.dq + b * p.dq_sb + (long long)orow * p.dq_ss + h * p.dq_sh;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+            const int d = 32 * t + 8 * qd + 4 * half;
+            *reinterpret_cast<float4 *>(oa + d) = make_float4(accA[t][4 * qd], accA[t][4 * qd + 1], accA[t][4 * qd + 2], accA[t][4 * qd + 3]);
+        }
+    if constexpr (DKV) {
+        float *ob = p.dv + b * p.dv_sb + (long long)orow * p.dv_ss + h * p.dv_sh;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int qd = 0; qd < 4; ++qd) {
+                const int d = 32 * t + 8 * qd + 4 * half;
+                *reinterpret_cast<float4 *>(ob + d) = make_float4(accB[t][4 * qd], accB[t][4 * qd + 1], accB[t][4 * qd + 2], accB[t][4 * qd + 3]);
+            }
+    }
+}
+
 }  // namespace cer
 
 using namespace cer;
 
 extern "C" int cer_attention_fwd(const float *q, const float *k, const float *v, const int *key_mask, float *out,
-                                 int B, int H, int Sq, int Sk, int D, const long long *q_strides,
+                                 float *lse, int B, int H, int Sq, int Sk, int D, const long long *q_strides,
                                  const long long *k_strides, const long long *v_strides, const long long *o_strides,
                                  float scale, void *stream) {
     if (!q || !k || !v || !out || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 || !q_strides || !k_strides || !v_strides ||
@@ -157,7 +323,7 @@ extern "C" int cer_attention_fwd(const float *q, const float *k, const float *v,
         if ((q_strides[i] & 3) || (k_strides[i] & 3) || (v_strides[i] & 3) || (o_strides[i] & 3))
             return cer_set_error(CER_ERR_INVALID_ARG, "attention_fwd: strides must be multiples of 4 floats");
     AttnArgs a{};
-    a.q = q; a.k = k; a.v = v; a.key_mask = key_mask; a.out = out;
+    a.q = q; a.k = k; a.v = v; a.key_mask = key_mask; a.out = out; a.lse = lse;
     a.q_sb = q_strides[0]; a.q_ss = q_strides[1]; a.q_sh = q_strides[2];
     a.k_sb = k_strides[0]; a.k_ss = k_strides[1]; a.k_sh = k_strides[2];
     a.v_sb = v_strides[0]; a.v_ss = v_strides[1]; a.v_sh = v_strides[2];
@@ -168,6 +334,47 @@ extern "C" int cer_attention_fwd(const float *q, const float *k, const float *v,
     else if (D == 128) CER_LAUNCH(attention_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else if (D == 32) CER_LAUNCH(attention_fwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a);
     else return cer_set_error(CER_ERR_UNSUPPORTED, "attention_fwd: head dim must be 32, 64 or 128");
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+template <int D>
+static void launch_attn_bwd(const AttnBwdArgs &a, hipStream_t st) {
+    CER_LAUNCH((attention_bwd_kernel<D, false>), dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
+    CER_LAUNCH((attention_bwd_kernel<D, true>), dim3((a.Sk + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
+}
+
+extern "C" int cer_attention_bwd(const float *q, const float *k, const float *v, const float *out, const float *dout,
+                                 const float *lse, const int *key_mask, float *delta, float *dq, float *dk, float *dv,
+                                 int B, int H, int Sq, int Sk, int D, const long long *q_strides,
+                                 const long long *k_strides, const long long *v_strides, const long long *o_strides,
+                                 const long long *do_strides, const long long *dq_strides, const long long *dk_strides,
+                                 const long long *dv_strides, float scale, void *stream) {
+    if (!q || !k || !v || !out || !dout || !lse || !delta || !dq || !dk || !dv || B <= 0 || H <= 0 || Sq <= 0 || Sk <= 0 ||
+        !q_strides || !k_strides || !v_strides || !o_strides || !do_strides || !dq_strides || !dk_strides || !dv_strides)
+        return cer_set_error(CER_ERR_INVALID_ARG, "attention_bwd: bad argument");
+    const long long *all[] = {q_strides, k_strides, v_strides, o_strides, do_strides, dq_strides, dk_strides, dv_strides};
+    for (const long long *st : all)
+        for (int i = 0; i < 3; ++i)
+            if (st[i] & 3) return cer_set_error(CER_ERR_INVALID_ARG, "attention_bwd: strides must be multiples of 4 floats");
+    if (D != 32 && D != 64 && D != 128) return cer_set_error(CER_ERR_UNSUPPORTED, "attention_bwd: head dim must be 32, 64 or 128");
+    hipStream_t st = (hipStream_t)stream;
+    CER_LAUNCH(attn_delta_kernel, dim3((B * H * Sq + 3) / 4), dim3(256), 0, st, out, dout, delta, o_strides[0], o_strides[1],
+               o_strides[2], do_strides[0], do_strides[1], do_strides[2], B, H, Sq, D);
+    AttnBwdArgs a{};
+    a.q = q; a.k = k; a.v = v; a.dout = dout; a.lse = lse; a.delta = delta; a.key_mask = key_mask;
+    a.dq = dq; a.dk = dk; a.dv = dv;
+    a.q_sb = q_strides[0]; a.q_ss = q_strides[1]; a.q_sh = q_strides[2];
+    a.k_sb = k_strides[0]; a.k_ss = k_strides[1]; a.k_sh = k_strides[2];
+    a.v_sb = v_strides[0]; a.v_ss = v_strides[1]; a.v_sh = v_strides[2];
+    a.o_sb = do_strides[0]; a.o_ss = do_strides[1]; a.o_sh = do_strides[2];
+    a.dq_sb = dq_strides[0]; a.dq_ss = dq_strides[1]; a.dq_sh = dq_strides[2];
+    a.dk_sb = dk_strides[0]; a.dk_ss = dk_strides[1]; a.dk_sh = dk_strides[2];
+    a.dv_sb = dv_strides[0]; a.dv_ss = dv_strides[1]; a.dv_sh = dv_strides[2];
+    a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.scale = scale;
+    if (D == 32) launch_attn_bwd<32>(a, st);
+    else if (D == 64) launch_attn_bwd<64>(a, st);
+    else launch_attn_bwd<128>(a, st);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }

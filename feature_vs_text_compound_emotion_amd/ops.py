@@ -392,7 +392,8 @@ def bert_embed_ln(ids, word, pos, typ, gamma, beta, eps=1e-12):
     return y
 
 
-def attention(q, k, v, out, batch, heads, sq, sk, d, q_strides, k_strides, v_strides, o_strides, scale, key_mask=None):
+def attention(q, k, v, out, batch, heads, sq, sk, d, q_strides, k_strides, v_strides, o_strides, scale, key_mask=None,
+              lse=None):
     """Strided attention: element (b, s, h, :) at base + b*st[0] + s*st[1] + h*st[2].  q/k/v/out are
     (views into) float32 GPU buffers; only their data pointers are used."""
     for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out")):
@@ -401,10 +402,25 @@ def attention(q, k, v, out, batch, heads, sq, sk, d, q_strides, k_strides, v_str
     if key_mask is not None and not (key_mask.is_cuda and key_mask.dtype == torch.int32 and key_mask.is_contiguous()):
         raise ValueError("key_mask: expected a contiguous int32 GPU tensor [B, Sk]")
     LL3 = ctypes.c_longlong * 3
-    check(_lib.load().cer_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(key_mask), ptr(out), batch, heads, sq, sk, d,
+    check(_lib.load().cer_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(key_mask), ptr(out), ptr(lse), batch, heads, sq, sk, d,
                                         LL3(*q_strides), LL3(*k_strides), LL3(*v_strides), LL3(*o_strides), scale,
                                         current_stream()), "cer_attention_fwd")
     return out
+
+
+def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, batch, heads, sq, sk, d, q_strides, k_strides, v_strides,
+                  o_strides, do_strides, dq_strides, dk_strides, dv_strides, scale, key_mask=None):
+    """Gradients of ``attention`` written into dq/dk/dv (views allowed, strides given explicitly)."""
+    for t, n in ((q, "q"), (k, "k"), (v, "v"), (out, "out"), (dout, "dout"), (lse, "lse"), (dq, "dq"), (dk, "dk"), (dv, "dv")):
+        if not (t.is_cuda and t.dtype == torch.float32):
+            raise ValueError(f"{n}: expected a float32 GPU tensor")
+    LL3 = ctypes.c_longlong * 3
+    delta = torch.empty_like(lse)
+    check(_lib.load().cer_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(key_mask), ptr(delta),
+                                        ptr(dq), ptr(dk), ptr(dv), batch, heads, sq, sk, d, LL3(*q_strides),
+                                        LL3(*k_strides), LL3(*v_strides), LL3(*o_strides), LL3(*do_strides),
+                                        LL3(*dq_strides), LL3(*dk_strides), LL3(*dv_strides), scale, current_stream()),
+          "cer_attention_bwd")
 
 
 def add_inplace(y, x):

@@ -212,9 +212,18 @@ int cer_bert_embed_ln(const long long *ids, const float *word, const float *pos,
  * Element (b, s, h, d) of a tensor sits at ptr + b*strides[0] + s*strides[1] + h*strides[2] + d.
  * key_mask [B][Sk] (1 = attend) or NULL.  D in {32, 64, 128}.  Replaces BertSelfAttention and the
  * nn.MultiheadAttention of the JMT/MT heads (reference models/model.py:716-750, 967-972). */
-int cer_attention_fwd(const float *q, const float *k, const float *v, const int *key_mask, float *out,
+int cer_attention_fwd(const float *q, const float *k, const float *v, const int *key_mask, float *out, float *lse,
                       int B, int H, int Sq, int Sk, int D, const long long *q_strides, const long long *k_strides,
                       const long long *v_strides, const long long *o_strides, float scale, void *stream);
+/* Backward of cer_attention_fwd (JMT/MT heads train through nn.MultiheadAttention).  lse [B,H,Sq] is the
+ * forward's optional output; delta [B,H,Sq] is scratch.  Two recompute passes (one owning queries, one
+ * owning keys), no atomics: deterministic. */
+int cer_attention_bwd(const float *q, const float *k, const float *v, const float *out, const float *dout,
+                      const float *lse, const int *key_mask, float *delta, float *dq, float *dk, float *dv,
+                      int B, int H, int Sq, int Sk, int D, const long long *q_strides, const long long *k_strides,
+                      const long long *v_strides, const long long *o_strides, const long long *do_strides,
+                      const long long *dq_strides, const long long *dk_strides, const long long *dv_strides,
+                      float scale, void *stream);
 
 /* y += x */
 int cer_add_inplace(float *y, const float *x, size_t n, void *stream);
