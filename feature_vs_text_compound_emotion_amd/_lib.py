@@ -56,6 +56,9 @@ _SIGNATURES = {
     "cer_cross_entropy": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "cer_dropout_mask": (c_int, [_P, c_size_t, c_float, c_uint64, c_uint64, _P]),
     "cer_copy_cols": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
+    "cer_leaky_relu_fwd": (c_int, [_P, _P, c_size_t, c_float, _P]),
+    "cer_softmax_gate_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "cer_softmax_gate_bwd": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     "cer_logmel_num_frames": (c_int, [c_int, c_int]),
     "cer_logmel_fwd": (c_int, [_P, c_int, c_int, c_int, _P, c_float, _P, _P]),
     "cer_frame_examples": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P]),

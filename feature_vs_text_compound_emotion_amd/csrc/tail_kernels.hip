@@ -386,11 +386,81 @@ __global__ void copy_cols_kernel(const float *__restrict__ x, int x_ld, float *_
     y[(size_t)r * y_ld + c] = x[(size_t)r * x_ld + c];
 }
 
+// y = x >= 0 ? x : slope * x
+__global__ void leaky_relu_fwd_kernel(const float4 *__restrict__ x, float4 *__restrict__ y, size_t n4, float slope) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    float4 v = x[i];
+    y[i] = make_float4(v.x >= 0.f ? v.x : v.x * slope, v.y >= 0.f ? v.y : v.y * slope, v.z >= 0.f ? v.z : v.z * slope,
+                       v.w >= 0.f ? v.w : v.w * slope);
+}
+
+// CAN attention fusion gate (reference models/model.py:561-566): out = softmax(z) * c, rows of C.
+// One wave per row; p is saved for the backward.
+__global__ void softmax_gate_fwd_kernel(const float *__restrict__ z, const float *__restrict__ c, float *__restrict__ out,
+                                        float *__restrict__ prob, int R, int C) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const float *zr = z + (size_t)row * C, *cr = c + (size_t)row * C;
+    float mx = -INFINITY;
+    for (int i = lane; i < C; i += 64) mx = fmaxf(mx, zr[i]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float s = 0.f;
+    for (int i = lane; i < C; i += 64) s += expf(zr[i] - mx);
+    s = wave_sum(s);
+    const float inv = 1.f / s;
+    for (int i = lane; i < C; i += 64) {
+        const float p = expf(zr[i] - mx) * inv;
+        prob[(size_t)row * C + i] = p;
+        out[(size_t)row * C + i] = p * cr[i];
+    }
+}
+
+// dc = dout * p;  dz = p * (dout*c - sum(p * dout * c))
+__global__ void softmax_gate_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ prob,
+                                        const float *__restrict__ c, float *__restrict__ dz, float *__restrict__ dc,
+                                        int R, int C) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= R) return;
+    const size_t o = (size_t)row * C;
+    float s = 0.f;
+    for (int i = lane; i < C; i += 64) s += prob[o + i] * dout[o + i] * c[o + i];
+    s = wave_sum(s);
+    for (int i = lane; i < C; i += 64) {
+        const float p = prob[o + i], g = dout[o + i];
+        dc[o + i] = g * p;
+        dz[o + i] = p * (g * c[o + i] - s);
+    }
+}
+
 }  // namespace cer
 
 using namespace cer;
 
 #define ST ((hipStream_t)stream)
+
+extern "C" int cer_leaky_relu_fwd(const float *x, float *y, size_t n, float slope, void *stream) {
+    if (!x || !y || n == 0 || (n & 3)) return cer_set_error(CER_ERR_INVALID_ARG, "leaky_relu_fwd: n must be a positive multiple of 4");
+    CER_LAUNCH(leaky_relu_fwd_kernel, dim3(cer_blocks(n / 4, 256)), dim3(256), 0, ST, (const float4 *)x, (float4 *)y, n / 4, slope);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+extern "C" int cer_softmax_gate_fwd(const float *z, const float *c, float *out, float *prob, int R, int C, void *stream) {
+    if (!z || !c || !out || !prob || R <= 0 || C <= 0) return cer_set_error(CER_ERR_INVALID_ARG, "softmax_gate_fwd: bad argument");
+    CER_LAUNCH(softmax_gate_fwd_kernel, dim3((R + 3) / 4), dim3(256), 0, ST, z, c, out, prob, R, C);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+extern "C" int cer_softmax_gate_bwd(const float *dout, const float *prob, const float *c, float *dz, float *dc, int R, int C,
+                                    void *stream) {
+    if (!dout || !prob || !c || !dz || !dc || R <= 0 || C <= 0) return cer_set_error(CER_ERR_INVALID_ARG, "softmax_gate_bwd: bad argument");
+    CER_LAUNCH(softmax_gate_bwd_kernel, dim3((R + 3) / 4), dim3(256), 0, ST, dout, prob, c, dz, dc, R, C);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
 
 extern "C" int cer_weight_norm_fwd(const float *v, const float *g, float *w, float *norm, int rows, int E, void *stream) {
     if (!v || !g || !w || !norm || rows <= 0 || E <= 0) return cer_set_error(CER_ERR_INVALID_ARG, "weight_norm_fwd: bad argument");

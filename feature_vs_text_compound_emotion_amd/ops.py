@@ -342,6 +342,31 @@ def dropout_mask(shape, p, seed, offset, device):
     return m
 
 
+def leaky_relu(x, slope=LEAKY_SLOPE):
+    _dev_f32(x, "x")
+    y = torch.empty_like(x)
+    check(_lib.load().cer_leaky_relu_fwd(ptr(x), ptr(y), x.numel(), slope, current_stream()), "cer_leaky_relu_fwd")
+    return y
+
+
+def softmax_gate_fwd(z, c):
+    _dev_f32(z, "z")
+    _dev_f32(c, "c")
+    out, prob = torch.empty_like(z), torch.empty_like(z)
+    check(_lib.load().cer_softmax_gate_fwd(ptr(z), ptr(c), ptr(out), ptr(prob), z.shape[0], z.shape[1], current_stream()),
+          "cer_softmax_gate_fwd")
+    return out, prob
+
+
+def softmax_gate_bwd(dout, prob, c):
+    for t, n in ((dout, "dout"), (prob, "prob"), (c, "c")):
+        _dev_f32(t, n)
+    dz, dc = torch.empty_like(dout), torch.empty_like(dout)
+    check(_lib.load().cer_softmax_gate_bwd(ptr(dout), ptr(prob), ptr(c), ptr(dz), ptr(dc), dout.shape[0], dout.shape[1],
+                                           current_stream()), "cer_softmax_gate_bwd")
+    return dz, dc
+
+
 def copy_cols(x, out):
     r, c, x_ld = _rows(x, "x")
     _, _, y_ld = _rows(out, "out")

@@ -109,6 +109,85 @@ def lfan_spec(modalities, n_cls=7, head_hw=5, kernel_size=5, modal_dim=32):
     return s, alias
 
 
+# configs.py:75-127 (tcn_settings used by CAN / JMT / MT)
+TCN_SETTINGS = {"video": {"input_dim": 512, "channel": [256, 256, 128, 128, 128], "kernel_size": 5},
+                "vggish": {"input_dim": 128, "channel": [128, 128, 64, 64], "kernel_size": 5},
+                "bert": {"input_dim": 768, "channel": [256, 256, 128, 128], "kernel_size": 5}}
+
+
+def _mha_spec(s, p, e=128):
+    s[p + "in_proj_weight"] = ((3 * e, e), "linear")
+    s[p + "in_proj_bias"] = ((3 * e,), "bias")
+    s[p + "out_proj.weight"] = ((e, e), "linear")
+    s[p + "out_proj.bias"] = ((e,), "bias")
+
+
+def _enc_layer_spec(s, p, e=128, hidden=128):
+    _mha_spec(s, p + "layers.0.attention.", e)
+    s[p + "layers.0.feed_forward.0.weight"] = ((hidden, e), "linear")
+    s[p + "layers.0.feed_forward.0.bias"] = ((hidden,), "bias")
+    s[p + "layers.0.feed_forward.2.weight"] = ((e, hidden), "linear")
+    s[p + "layers.0.feed_forward.2.bias"] = ((e,), "bias")
+    for ln in ("layer_norm1", "layer_norm2"):
+        s[p + f"layers.0.{ln}.weight"] = ((e,), "bn_w")
+        s[p + f"layers.0.{ln}.bias"] = ((e,), "bn_b")
+
+
+def _tail_common_spec(modalities, head_hw):
+    s, alias = OrderedDict(), {}
+    for m in modalities:
+        cfg = TCN_SETTINGS[m]
+        t, a = tcn_spec(f"temporal.{m}.", cfg["input_dim"], cfg["channel"], cfg["kernel_size"])
+        s.update(t)
+        alias.update(a)
+        _bn_spec(s, f"bn.{m}", cfg["channel"][-1])
+    if "video" in modalities:
+        s.update(visual_backbone_spec("spatial.visual.", head_hw))
+    return s, alias
+
+
+def jmt_spec(modalities=("video", "vggish"), model_name="JMT", n_cls=7, head_hw=5):
+    """JMT / MT keys (models/model.py:895-1167).  MTFusion keeps an unused reduce_feats_dim."""
+    s, alias = _tail_common_spec(modalities, head_hw)
+    f = "fuse."
+    encs = ["visual_encoder", "audio_encoder"] + (["jr_encoder"] if model_name == "JMT" else [])
+    for e in encs:
+        _enc_layer_spec(s, f + e + ".")
+    cas = ["CA_va", "CA_av"] + (["CA_jra", "CA_ajr", "CA_vjr", "CA_jrv"] if model_name == "JMT" else [])
+    for c in cas:
+        _mha_spec(s, f + c + ".")
+    s[f + "reduce_feats_dim.weight"] = ((128, 256), "linear")
+    s[f + "reduce_feats_dim.bias"] = ((128,), "bias")
+    s[f + "augment_audio_feats_dim.weight"] = ((128, 64), "linear")
+    s[f + "augment_audio_feats_dim.bias"] = ((128,), "bias")
+    _enc_layer_spec(s, f + "final_encoder.")
+    _mha_spec(s, f + "final_self_attention.")
+    _bn_spec(s, "bn1", 128)
+    for k, shp in (("fc1", (128, 128)), ("fc2", (n_cls, 128))):
+        s[k + ".weight"] = (shp, "linear")
+        s[k + ".bias"] = ((shp[0],), "bias")
+    return s, alias
+
+
+def can_spec(modalities=("video", "vggish"), n_cls=7, head_hw=5):
+    """CAN keys (models/model.py:529-684); conv_c is defined but never used by forward."""
+    s, alias = _tail_common_spec(modalities, head_hw)
+    m = len(modalities)
+    for i, mod in enumerate(modalities):
+        s[f"fuse.attn.{i}.weight"] = ((128, TCN_SETTINGS[mod]["channel"][-1]), "linear")
+        s[f"fuse.attn.{i}.bias"] = ((128,), "bias")
+    s["fuse.weights.weight"] = ((128 * m, 128 * m), "linear")
+    s["fuse.weights.bias"] = ((128 * m,), "bias")
+    s["conv_c.weight"] = ((128, 128 * m, 1), "conv")
+    s["conv_c.bias"] = ((128,), "bias")
+    _bn_spec(s, "bn1", 128 * m)
+    s["fc1.weight"] = ((128 * m, 128 * m), "linear")
+    s["fc1.bias"] = ((128 * m,), "bias")
+    s["fc2.weight"] = ((n_cls, 128 * m), "linear")
+    s["fc2.bias"] = ((n_cls,), "bias")
+    return s, alias
+
+
 VGGISH_CONVS = ((0, 1, 64), (3, 64, 128), (6, 128, 256), (8, 256, 256), (11, 256, 512), (13, 512, 512))
 
 

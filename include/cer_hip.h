@@ -231,6 +231,16 @@ int cer_add_inplace(float *y, const float *x, size_t n, void *stream);
 /* Pre-scaled dropout keep-mask, a pure function of (seed, offset + i). */
 int cer_dropout_mask(float *mask, size_t n, float p, uint64_t seed, uint64_t offset, void *stream);
 
+/* y = x >= 0 ? x : slope*x  (F.leaky_relu between fc1/bn1 and fc2 of the CAN / JMT heads,
+ * reference models/model.py:676,1160; backward = cer_act_mask_bwd). */
+int cer_leaky_relu_fwd(const float *x, float *y, size_t n, float slope, void *stream);
+
+/* CAN attention-fusion gate (reference models/model.py:561-566): out = softmax(z) * c over rows of C;
+ * prob is saved for the backward, which returns dz and dc. */
+int cer_softmax_gate_fwd(const float *z, const float *c, float *out, float *prob, int R, int C, void *stream);
+int cer_softmax_gate_bwd(const float *dout, const float *prob, const float *c, float *dz, float *dc, int R, int C,
+                         void *stream);
+
 /* y[r, 0:C] (pitch y_ld) = x[r, 0:C] (pitch x_ld). */
 int cer_copy_cols(const float *x, int x_ld, float *y, int y_ld, int R, int C, void *stream);
 

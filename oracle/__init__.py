@@ -24,3 +24,4 @@ from .fusion import lfan_fusion_forward  # noqa: F401
 from .lfan import lfan_forward, cross_entropy_mean, sgd_nesterov_step  # noqa: F401
 from .vggish import vggish_forward, waveform_to_examples, wav_int16_to_examples, log_mel_spectrogram  # noqa: F401,E402
 from .bert import bert_hidden_states, bert_token_features, exclude_padding  # noqa: F401,E402
+from .jmt import jmt_forward, can_forward, jmt_fusion  # noqa: F401,E402

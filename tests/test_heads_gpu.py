@@ -1,0 +1,70 @@
+"""CAN / JMT / MT heads on the HIP kernels vs fixtures recorded from the reference's classes."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import golden  # noqa: E402
+
+MODS = ["video", "vggish"]
+
+
+def _build(name, sd):
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.fusion_heads import CAN, JMT
+    if name == "CAN":
+        m = CAN(task="CLASSIFICATION", modalities=MODS, tcn_settings=synth.TCN_SETTINGS, backbone_settings={}, output_dim=7,
+                root_dir="", device="cuda", load_backbone=False)
+    else:
+        m = JMT(task="CLASSIFICATION", modalities=MODS, tcn_settings=synth.TCN_SETTINGS, backbone_settings={}, output_dim=7,
+                root_dir="", device="cuda", model_name=name, load_backbone=False)
+    assert set(m.state_dict()) == set(sd), set(m.state_dict()) ^ set(sd)
+    m.load_state_dict(sd, strict=True)
+    return m.cuda()
+
+
+@pytest.mark.parametrize("name", ["JMT", "MT", "CAN"])
+def test_head_eval_and_training_step_match_reference_fixture(name):
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.lfan import cross_entropy_loss
+    g = golden("heads_can_jmt_mt.npz")
+    b, l, hw, ncls, wseed, dseed = [int(v) for v in g["meta"]]
+    spec, alias = synth.can_spec(MODS) if name == "CAN" else synth.jmt_spec(MODS, name)
+    sd = synth.make_state_dict(spec, alias, seed=wseed)
+    x, labels = synth.make_clip_batch(MODS, b, l, hw=hw, seed=dseed)
+    xd = {k: v.cuda() for k, v in x.items()}
+    model = _build(name, sd).eval()
+    with torch.no_grad():
+        logits = model(xd)
+    assert np.abs(logits.cpu().numpy() - g[f"{name}_eval_logits"]).max() < 1e-4
+    # one optimisation step exactly as the reference runs it (model.train()), dropout off
+    model = _build(name, sd).train()
+    for net in model.temporal.values():
+        net.dropout = 0.0
+    for mod in model.modules():
+        if isinstance(mod, torch.nn.Dropout):
+            mod.p = 0.0
+    out = model(xd)
+    loss = cross_entropy_loss(out, labels.cuda())
+    loss.backward()
+    assert abs(loss.item() - float(g[f"{name}_train_loss"])) < 1e-4
+    assert np.abs(out.detach().cpu().numpy() - g[f"{name}_train_logits"]).max() < 2e-4
+    named = dict(model.named_parameters())
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    assert names == list(g[f"{name}_names"])
+    gn = np.array([0.0 if named[n].grad is None else named[n].grad.norm().item() for n in names])
+    ref = g[f"{name}_gradnorm"]
+    assert np.abs(gn - ref).max() < 5e-4 * max(1.0, np.abs(ref).max())
+    for key in g.files:
+        if key.startswith(f"{name}_grad:"):
+            got = named[key.split(":", 1)[1]].grad.cpu().numpy()
+            assert np.abs(got - g[key]).max() < 2e-4 * max(1.0, np.abs(g[key]).max()), key
+
+
+def test_jmt_rejects_other_modalities():
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.fusion_heads import JMT
+    with pytest.raises(ValueError):
+        JMT(task="CLASSIFICATION", modalities=["video", "bert"], tcn_settings=synth.TCN_SETTINGS, backbone_settings={},
+            output_dim=7, root_dir="", device="cuda", model_name="JMT", load_backbone=False)

@@ -119,3 +119,17 @@ def test_bert_features_match_transformers():
     with torch.no_grad():
         feats = oracle.exclude_padding(oracle.bert_token_features(ids2, mask2, bsd), mask2)
     assert np.abs(feats.numpy()[:, ::8] - g["feats_excl"]).max() < 2e-4
+
+
+def test_can_jmt_mt_heads_match_reference():
+    from oracle.jmt import can_forward, jmt_forward
+    g = golden("heads_can_jmt_mt.npz")
+    b, l, hw, ncls, wseed, dseed = [int(v) for v in g["meta"]]
+    mods = ["video", "vggish"]
+    x, _ = synth.make_clip_batch(mods, b, l, hw=hw, seed=dseed)
+    for name in ("JMT", "MT", "CAN"):
+        spec, alias = synth.can_spec(mods) if name == "CAN" else synth.jmt_spec(mods, name)
+        sd = synth.make_state_dict(spec, alias, seed=wseed)
+        with torch.no_grad():
+            out = can_forward(x, sd, mods) if name == "CAN" else jmt_forward(x, sd, mods, model_name=name)
+        assert np.abs(out.numpy() - g[f"{name}_eval_logits"]).max() < TOL
