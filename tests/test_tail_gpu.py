@@ -273,3 +273,28 @@ def test_lfan_train_forward_with_reference_dropout_masks_matches_fixture():
     assert np.abs(sd_after["bn.video.running_var"].cpu().numpy() - g["bn_video_running_var"]).max() < 1e-5
     assert np.abs(sd_after["spatial.visual.backbone.input_layer.1.running_mean"].cpu().numpy()
                   - g["stem_running_mean"]).max() < 1e-5
+
+
+def test_trainer_windowed_inference_on_hip_model_vs_oracle():
+    """A 21-frame video through a window-8 / hop-5 LFAN: slide, forward on the GPU, stitch, average."""
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.trainer import Trainer, windowing
+    from oracle.lfan import lfan_forward
+    mods = ["vggish", "bert"]
+    sd = synth.lfan_state_dict(mods, n_cls=7, seed=9)
+    model = _build_lfan(mods, sd, 8).eval()
+    n = 21
+    g = torch.Generator().manual_seed(77)
+    X = {"vggish": torch.randn(1, 1, n, 128, generator=g), "bert": torch.randn(1, 1, n, 768, generator=g),
+         "EXPR_continuous_label": torch.full((1, n, 1), 3.0)}
+    tr = Trainer(model, device="cuda", window_length=8, hop_length=5, number_classes=7)
+    perf, per_video = tr.inference([(X, ["clip0"], [n], [np.arange(n)])])
+    acc = np.zeros((n, 7))
+    cnt = np.zeros(n)
+    for wd in windowing(np.arange(n), 8, 5):
+        with torch.no_grad():
+            o = lfan_forward({m: X[m][:, :, wd] for m in mods}, sd, mods)
+        acc[wd] += o[0].numpy()
+        cnt[wd] += 1
+    assert np.abs(per_video["clip0"]["logits"] - acc / cnt[:, None]).max() < 1e-4
+    assert per_video["clip0"]["labels"].tolist() == [3] * n

@@ -1,0 +1,115 @@
+"""Host logic of the trainer mirror: window rules, overlap stitching, inference bookkeeping, metrics.
+Runs on the CPU with a stub model (the HIP model itself is covered by the gpu tests)."""
+import numpy as np
+import torch
+
+from feature_vs_text_compound_emotion_amd import metrics
+from feature_vs_text_compound_emotion_amd.trainer import Trainer, dataset_windowing, windowing
+
+
+def test_window_rules_differ_at_exact_length():
+    x = np.arange(300)
+    assert len(windowing(x, 300, 200)) == 1 and len(dataset_windowing(x, 300, 200)) == 1
+    assert [w[0] for w in windowing(np.arange(301), 300, 200)] == [0, 1]          # tail window appended
+    assert [(w[0], w[-1]) for w in windowing(np.arange(700), 300, 200)] == [(0, 299), (200, 499), (400, 699)]
+    assert [(w[0], w[-1]) for w in windowing(np.arange(650), 300, 200)] == [(0, 299), (200, 499), (350, 649)]
+    # `>=` (trainer) vs `>` (dataset) only matters for the returned object at n == window_length
+    assert windowing(x, 300, 200)[0] is not x and dataset_windowing(x, 300, 200)[0] is x
+    assert len(windowing(np.arange(10), 300, 200)) == 1
+
+
+class _Stub(torch.nn.Module):
+    """logits[b, t, c] = frame_value[b, t] * (c + 1) + window bias, so stitched averages are predictable."""
+
+    def __init__(self, ncls=7):
+        super().__init__()
+        self.ncls, self.calls = ncls, 0
+
+    def forward(self, X):
+        self.calls += 1
+        v = X["vggish"][:, 0, :, 0]  # [B, L]
+        return v.unsqueeze(-1) * torch.arange(1, self.ncls + 1, dtype=torch.float32).view(1, 1, -1) + self.calls
+
+
+def test_windowed_inference_scatter_add_and_average():
+    n, win, hop = 650, 300, 200
+    tr = Trainer(_Stub(), device="cpu", window_length=win, hop_length=hop)
+    data = {"vggish": torch.arange(n, dtype=torch.float32).view(1, 1, n, 1).repeat(1, 1, 1, 128),
+            "video": torch.zeros(1, n, 3, 4, 4)}
+    out = tr.inference_forward_windows(data)
+    assert tuple(out.shape) == (1, n, 7)
+    starts = [0, 200, 350]
+    expect = np.zeros((n, 7))
+    count = np.zeros(n)
+    for call, s in enumerate(starts, start=1):
+        t = np.arange(s, s + win)
+        expect[t] += t[:, None] * np.arange(1, 8)[None] + call
+        count[t] += 1
+    assert np.allclose(out[0].numpy(), expect / count[:, None], atol=1e-4)
+
+
+def test_inference_loop_and_metrics():
+    ncls = 7
+    tr = Trainer(_Stub(ncls), device="cpu", window_length=8, hop_length=4, number_classes=ncls)
+
+    def loader():
+        for vid, (n, label) in enumerate([(6, 6), (13, 6), (8, 6)]):
+            X = {"vggish": torch.ones(1, 1, n, 128), "video": torch.zeros(1, n, 3, 4, 4),
+                 "EXPR_continuous_label": torch.full((1, n, 1), float(label))}
+            yield X, [f"v{vid}"], [n], [np.arange(n)]
+    perf, per_video = tr.inference(list(loader()))
+    assert set(per_video) == {"v0", "v1", "v2"} and per_video["v1"]["logits"].shape == (13, ncls)
+    # the stub's logits grow with the class index -> every frame predicts the last class (6) == label
+    p = perf[None]
+    assert p[metrics.CL_ACC][metrics.FRAME_LEVEL]["master"] == 100.0
+    assert p[metrics.W_F1][metrics.VIDEO_LEVEL][metrics.FRM_VOTE]["master"] == 1.0
+
+
+def test_f1_definitions_match_sklearn_when_available():
+    rng = np.random.default_rng(0)
+    trg, prd = rng.integers(0, 7, 500).tolist(), rng.integers(0, 8, 500).tolist()
+    f1s, macro = metrics.compute_f1_score(trg, prd, metrics.MACRO_F1)
+    _, w = metrics.compute_f1_score(trg, prd, metrics.W_F1)
+    try:
+        from sklearn.metrics import confusion_matrix, f1_score
+    except Exception:  # pragma: no cover
+        return
+    assert np.allclose(f1s, f1_score(trg, prd, average=None))
+    assert abs(macro - np.mean(f1_score(trg, prd, average=None))) < 1e-12
+    assert abs(w - f1_score(trg, prd, average="weighted")) < 1e-12
+    assert np.allclose(metrics.compute_confusion_matrix(trg, prd), confusion_matrix(trg, prd, normalize="true"))
+
+
+def test_video_level_aggregations_and_other_class():
+    logits = np.array([[2.0, 1.0, 0.0, 9.0], [0.0, 3.0, 0.0, 9.0], [0.0, 3.1, 0.0, 9.0]])
+    data = {"a": {"labels": np.array([1, 1, 1]), "logits": logits},
+            "b": {"labels": np.array([3, 3, 3]), "logits": logits}}
+    preds, trgs = metrics.format_trg_pred_video(data, None)
+    assert trgs == [1, 3] and preds[0][metrics.FRM_VOTE] == 3
+    # hypothetical 'Other' = last class with id 7 in the reference; here exercise the drop-last-class path
+    data7 = {"a": {"labels": np.array([1, 1]), "logits": np.eye(8)[[1, 7]] * 5}, "b": {"labels": np.array([7, 7]), "logits": np.eye(8)[[7, 7]]}}
+    preds, trgs = metrics.format_trg_pred_video(data7, 7)
+    assert trgs == [1] and preds[0][metrics.FRM_AVG_LOGITS] == 1
+    fp, ft = metrics.format_trg_pred_frames(data7, 7)
+    assert ft == [1, 1] and fp[0] == 1
+
+
+def test_train_step_on_cpu_stub_model():
+    model = torch.nn.Sequential()
+    lin = torch.nn.Linear(128, 7)
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = lin
+
+        def forward(self, X):
+            return self.lin(X["vggish"][:, 0])
+    m = M()
+    opt = torch.optim.SGD(m.parameters(), momentum=0.9, nesterov=True, weight_decay=1e-4)
+    crit = lambda o, l: torch.nn.functional.cross_entropy(o, l.long())  # noqa: E731
+    tr = Trainer(m, optimizer=opt, criterion=crit, device="cpu", number_classes=7, train_batch_size=2)
+    X = {"vggish": torch.randn(2, 1, 5, 128), "EXPR_continuous_label": torch.randint(0, 7, (2, 5, 1)).float()}
+    l0 = tr.train_step(X).item()
+    l1 = tr.train_step(X).item()
+    assert l1 < l0
