@@ -54,6 +54,21 @@ def build_model(hw, length, device):
     return model.to(device), sd
 
 
+def measured_traffic(hw, batch, length, encoders):
+    """HBM bytes per step of cer::conv_igemm_kernel from the committed rocprofv3 PMC passes
+    (tools/collect_traffic.py: FETCH_SIZE x2 + WRITE_SIZE, separate passes, gfx950 corrections).  PMC
+    counters cannot be read from inside the timed process, so the value is looked up by configuration
+    and is null when no profile of this exact configuration has been committed."""
+    path = os.path.join(ROOT, "profiles", f"round1_traffic_hw{hw}.json")
+    try:
+        t = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    if (str(t.get("batch")), str(t.get("length")), t.get("encoders")) != (str(batch), str(length), encoders):
+        return None
+    return t["hbm_bytes_per_step"]
+
+
 def host_threads():
     """Threads for the CPU baseline.  The GPU box gives a job a CFS quota (cpu.max) far below the
     visible CPU count; torch's default of one thread per visible CPU then gets throttled (measured on
@@ -254,7 +269,11 @@ def main():
             "roofline": {"bound": "mfma", "kernel": "cer::conv_igemm_kernel (IR-50 forward: 52 implicit-GEMM convs + head FC, "
                                                     "v_mfma_f32_32x32x2_f32)",
                          "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                         "traffic": measured_traffic(a.hw, a.batch, a.length, a.encoders),
+                         "traffic_note": "HBM bytes per step over all conv_igemm launches (rocprofv3 PMC, "
+                                         "profiles/round1_traffic_hw*.json); algorithmic minimum is "
+                                         "18.6 MB/frame @40x40, 584 MB/frame @224x224 (SURVEY 8d)",
                          "algorithmic_flops_per_step": flops, "ms_per_step_in_kernel": enc_ms},
         }
         if world == 1 and not a.no_cpu_baseline:

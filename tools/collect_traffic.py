@@ -1,0 +1,41 @@
+"""Reduce two rocprofv3 --pmc runs of bench.py (FETCH_SIZE and WRITE_SIZE, separate passes as
+MI355X_MICROARCH.md prescribes) to HBM bytes per step of cer::conv_igemm_kernel.
+
+gfx950 corrections (MI355X_MICROARCH.md, HBM section): FETCH_SIZE counts 64 B per 128-B request on wide
+coalesced reads -> doubled; WRITE_SIZE is exact for 16-B-per-lane stores; both are in KiB.
+
+    python tools/collect_traffic.py <fetch_dir> <write_dir> <steps_total> <out.json> [key=value ...]
+"""
+import csv
+import glob
+import json
+import sys
+
+
+def total(d, counter):
+    f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
+    s, n = 0.0, 0
+    for r in csv.DictReader(open(f)):
+        if "conv_igemm_kernel" in r["Kernel_Name"] and r["Counter_Name"] == counter:
+            s += float(r["Counter_Value"])
+            n += 1
+    return s, n
+
+
+def main():
+    fetch_dir, write_dir, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
+    extra = dict(kv.split("=", 1) for kv in sys.argv[5:])
+    f, nf = total(fetch_dir, "FETCH_SIZE")
+    w, nw = total(write_dir, "WRITE_SIZE")
+    res = {"kernel": "cer::conv_igemm_kernel (all launches of one step)", "steps_profiled": steps,
+           "launches_per_step": nf / steps,
+           "fetch_bytes_per_step": 2.0 * f * 1024 / steps, "write_bytes_per_step": w * 1024 / steps,
+           "hbm_bytes_per_step": (2.0 * f + w) * 1024 / steps,
+           "raw": {"FETCH_SIZE_KiB_sum": f, "WRITE_SIZE_KiB_sum": w, "dispatches": [nf, nw]},
+           "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE x1, KiB -> bytes", **extra}
+    json.dump(res, open(out, "w"), indent=1)
+    print(json.dumps(res))
+
+
+if __name__ == "__main__":
+    main()
