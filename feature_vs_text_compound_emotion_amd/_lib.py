@@ -23,13 +23,24 @@ class ConvDesc(Structure):
 
 
 _P = c_void_p
+
+
+class ConvIO(Structure):
+    """cer_conv_io: every pointer of one conv launch (see include/cer_hip.h)."""
+    _fields_ = [(n, c_void_p) for n in (
+        "x", "w", "x_hi", "x_lo", "w_hi", "w_lo", "in_scale", "in_shift", "bias", "alpha", "residual", "mask",
+        "res_hi", "res_lo", "y", "aux", "stats", "y_hi", "y_lo", "s2", "t2", "y2_hi", "y2_lo")]
+
+
 _SIGNATURES = {
     # name: (restype, argtypes)
     "cer_last_error": (c_char_p, []),
     "cer_version": (c_int, []),
     "cer_conv_kpad": (c_int, [c_int, c_int, c_int]),
     "cer_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
-    "cer_conv2d_stats_tiles": (c_int, [POINTER(ConvDesc)]),
+    "cer_conv2d_stats_tiles": (c_int, [POINTER(ConvDesc), c_int]),
+    "cer_conv2d_run": (c_int, [POINTER(ConvDesc), POINTER(ConvIO), _P, c_size_t, _P]),
+    "cer_split_bf16": (c_int, [_P, _P, _P, c_size_t, _P]),
     "cer_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "cer_bn_finalize_workspace_bytes": (c_size_t, [c_int, c_int]),
     "cer_bn_finalize": (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, c_size_t,

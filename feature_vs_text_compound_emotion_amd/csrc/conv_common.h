@@ -1,0 +1,142 @@
+// conv_common.h -- argument block and fused epilogue shared by the fp32 and the bf16x3
+// implicit-GEMM kernels (conv_igemm.hip, conv_b3.hip) and by the split-K reducer.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "cer_internal.h"
+
+namespace cer {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int PITCH = 36;  // floats per LDS row
+
+struct ConvArgs {
+    const float *x, *w, *in_scale, *in_shift, *bias, *alpha, *res, *mask;
+    float *y;        // output, or split-K partial slabs [split][M][Cout]
+    float *aux;      // optional [M][Cout]: mask*act1(conv+bias), i.e. the value before the residual add
+    float *stats;    // optional [tiles_m][2][Cout]: per-tile sum / sum of squares of the RAW conv result
+    // ---- split-bf16 ("bf16x3") operands and outputs: a value v is carried as hi = bf16(v),
+    // lo = bf16(v - hi); products use hi*hi + hi*lo + lo*hi on the bf16 matrix cores ----
+    const uint16_t *x_hi, *x_lo, *w_hi, *w_lo;  // b3 kernel inputs (x/w above are unused then)
+    const uint16_t *res_hi, *res_lo;            // residual given as a split tensor (alternative to res)
+    uint16_t *y_hi, *y_lo;                      // optional split copy of the output
+    const float *s2, *t2;                       // optional second output: out * s2[c] + t2[c] ...
+    uint16_t *y2_hi, *y2_lo;                    // ... stored split (the NEXT layer's pre-conv BatchNorm)
+    int x_ld, y_ld;  // row pitches (elements) of x pixels / y rows
+    int N, H, W, Cin, Ho, Wo, Cout;
+    int KH, KW, stride, dil_h, dil_w, pad_t, pad_l;
+    int x_nchw, res_stride, Hr, Wr, act1, act2;
+    float slope;
+    int Kpad, M, tiles_m, tiles_n, steps, steps_per_split, split_k, cin_steps;
+};
+
+template <int I> struct IdxC { static constexpr int v = I; };
+template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
+    if constexpr (N > 0) {
+        static_for<N - 1>(f);
+        f(IdxC<N - 1>{});
+    }
+}
+
+// bf16 <-> f32 bit helpers; the split is round-to-nearest-even (the hardware cvt) on both parts
+__device__ __forceinline__ float bf16_to_f32(uint16_t h) { return __uint_as_float((uint32_t)h << 16); }
+__device__ __forceinline__ uint16_t f32_to_bf16(float f) {
+    const __bf16 b = (__bf16)f;
+    return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ void split_bf16(float v, uint16_t &hi, uint16_t &lo) {
+    hi = f32_to_bf16(v);
+    lo = f32_to_bf16(v - bf16_to_f32(hi));
+}
+__device__ __forceinline__ void store_split4(uint16_t *hi, uint16_t *lo, const float o[4]) {
+    ushort4 h, l;
+    split_bf16(o[0], h.x, l.x); split_bf16(o[1], h.y, l.y);
+    split_bf16(o[2], h.z, l.z); split_bf16(o[3], h.w, l.w);
+    *reinterpret_cast<ushort4 *>(hi) = h;
+    *reinterpret_cast<ushort4 *>(lo) = l;
+}
+
+__device__ __forceinline__ float act_apply(float v, int act, float a, float slope) {
+    switch (act) {
+        case CER_ACT_PRELU: return v >= 0.f ? v : v * a;
+        case CER_ACT_LEAKY: return v >= 0.f ? v : v * slope;
+        case CER_ACT_RELU: return v > 0.f ? v : 0.f;
+        case CER_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
+        default: return v;
+    }
+}
+
+// Shared epilogue for the fused path and the split-K reducer.
+// v: 4 consecutive couts starting at c for output row m.
+__device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c, float v[4]) {
+    const bool vec = ((p.Cout & 3) == 0);
+    size_t roff = 0;
+    if (p.res || p.res_hi) {
+        if (p.res_stride == 1 && p.Hr == p.Ho && p.Wr == p.Wo) {
+            roff = (size_t)m * p.Cout;
+        } else {
+            int hw = p.Ho * p.Wo;
+            int n = m / hw, r = m - n * hw;
+            int ho = r / p.Wo, wo = r - ho * p.Wo;
+            roff = ((size_t)(n * p.Hr + ho * p.res_stride) * p.Wr + wo * p.res_stride) * p.Cout;
+        }
+    }
+    const size_t yoff = (size_t)m * p.y_ld + c;
+    const size_t doff = (size_t)m * p.Cout + c;  // dense offset (mask, aux)
+    if (vec && ((p.y_ld & 3) == 0) && c + 3 < p.Cout) {
+        float4 b = p.bias ? *reinterpret_cast<const float4 *>(p.bias + c) : make_float4(0, 0, 0, 0);
+        float4 a = (p.act1 == CER_ACT_PRELU) ? *reinterpret_cast<const float4 *>(p.alpha + c) : make_float4(0, 0, 0, 0);
+        float bb[4] = {b.x, b.y, b.z, b.w}, aa[4] = {a.x, a.y, a.z, a.w};
+        float rr[4] = {0, 0, 0, 0}, mm[4] = {1, 1, 1, 1};
+        if (p.res) {
+            float4 r = *reinterpret_cast<const float4 *>(p.res + roff + c);
+            rr[0] = r.x; rr[1] = r.y; rr[2] = r.z; rr[3] = r.w;
+        } else if (p.res_hi) {
+            const ushort4 h = *reinterpret_cast<const ushort4 *>(p.res_hi + roff + c);
+            const ushort4 l = *reinterpret_cast<const ushort4 *>(p.res_lo + roff + c);
+            rr[0] = bf16_to_f32(h.x) + bf16_to_f32(l.x); rr[1] = bf16_to_f32(h.y) + bf16_to_f32(l.y);
+            rr[2] = bf16_to_f32(h.z) + bf16_to_f32(l.z); rr[3] = bf16_to_f32(h.w) + bf16_to_f32(l.w);
+        }
+        if (p.mask) {
+            float4 k = *reinterpret_cast<const float4 *>(p.mask + doff);
+            mm[0] = k.x; mm[1] = k.y; mm[2] = k.z; mm[3] = k.w;
+        }
+        float o[4], u[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float t = act_apply(v[e] + bb[e], p.act1, aa[e], p.slope) * mm[e];
+            u[e] = t;
+            o[e] = act_apply(t + rr[e], p.act2, 0.f, p.slope);
+        }
+        if (p.aux) *reinterpret_cast<float4 *>(p.aux + doff) = make_float4(u[0], u[1], u[2], u[3]);
+        if (p.y) *reinterpret_cast<float4 *>(p.y + yoff) = make_float4(o[0], o[1], o[2], o[3]);
+        if (p.y_hi) store_split4(p.y_hi + yoff, p.y_lo + yoff, o);
+        if (p.y2_hi) {
+            const float4 s2 = *reinterpret_cast<const float4 *>(p.s2 + c), t2 = *reinterpret_cast<const float4 *>(p.t2 + c);
+            float o2[4] = {o[0] * s2.x + t2.x, o[1] * s2.y + t2.y, o[2] * s2.z + t2.z, o[3] * s2.w + t2.w};
+            store_split4(p.y2_hi + yoff, p.y2_lo + yoff, o2);
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            if (c + e < p.Cout) {
+                float t = v[e] + (p.bias ? p.bias[c + e] : 0.f);
+                t = act_apply(t, p.act1, p.act1 == CER_ACT_PRELU ? p.alpha[c + e] : 0.f, p.slope);
+                if (p.mask) t *= p.mask[doff + e];
+                if (p.aux) p.aux[doff + e] = t;
+                if (p.res) t += p.res[roff + c + e];
+                else if (p.res_hi) t += bf16_to_f32(p.res_hi[roff + c + e]) + bf16_to_f32(p.res_lo[roff + c + e]);
+                const float o = act_apply(t, p.act2, 0.f, p.slope);
+                if (p.y) p.y[yoff + e] = o;
+                if (p.y_hi) split_bf16(o, p.y_hi[yoff + e], p.y_lo[yoff + e]);
+                if (p.y2_hi) split_bf16(o * p.s2[c + e] + p.t2[c + e], p.y2_hi[yoff + e], p.y2_lo[yoff + e]);
+            }
+        }
+    }
+}
+
+
+}  // namespace cer

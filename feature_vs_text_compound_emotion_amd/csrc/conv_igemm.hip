@@ -22,98 +22,9 @@
 #include <stdint.h>
 
 #include "cer_internal.h"
+#include "conv_common.h"
 
 namespace cer {
-
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int BK = 32;
-constexpr int PITCH = 36;  // floats per LDS row
-
-struct ConvArgs {
-    const float *x, *w, *in_scale, *in_shift, *bias, *alpha, *res, *mask;
-    float *y;        // output, or split-K partial slabs [split][M][Cout]
-    float *aux;      // optional [M][Cout]: mask*act1(conv+bias), i.e. the value before the residual add
-    float *stats;    // optional [tiles_m][2][Cout]: per-tile sum / sum of squares of the RAW conv result
-    int x_ld, y_ld;  // row pitches (floats) of x pixels / y rows
-    int N, H, W, Cin, Ho, Wo, Cout;
-    int KH, KW, stride, dil_h, dil_w, pad_t, pad_l;
-    int x_nchw, res_stride, Hr, Wr, act1, act2;
-    float slope;
-    int Kpad, M, tiles_m, tiles_n, steps, steps_per_split, split_k, cin_steps;
-};
-
-template <int I> struct IdxC { static constexpr int v = I; };
-template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
-    if constexpr (N > 0) {
-        static_for<N - 1>(f);
-        f(IdxC<N - 1>{});
-    }
-}
-
-__device__ __forceinline__ float act_apply(float v, int act, float a, float slope) {
-    switch (act) {
-        case CER_ACT_PRELU: return v >= 0.f ? v : v * a;
-        case CER_ACT_LEAKY: return v >= 0.f ? v : v * slope;
-        case CER_ACT_RELU: return v > 0.f ? v : 0.f;
-        case CER_ACT_GELU: return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f));
-        default: return v;
-    }
-}
-
-// Shared epilogue for the fused path and the split-K reducer.
-// v: 4 consecutive couts starting at c for output row m.
-__device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c, float v[4]) {
-    const bool vec = ((p.Cout & 3) == 0);
-    size_t roff = 0;
-    if (p.res) {
-        if (p.res_stride == 1 && p.Hr == p.Ho && p.Wr == p.Wo) {
-            roff = (size_t)m * p.Cout;
-        } else {
-            int hw = p.Ho * p.Wo;
-            int n = m / hw, r = m - n * hw;
-            int ho = r / p.Wo, wo = r - ho * p.Wo;
-            roff = ((size_t)(n * p.Hr + ho * p.res_stride) * p.Wr + wo * p.res_stride) * p.Cout;
-        }
-    }
-    const size_t yoff = (size_t)m * p.y_ld + c;
-    const size_t doff = (size_t)m * p.Cout + c;  // dense offset (mask, aux)
-    if (vec && ((p.y_ld & 3) == 0) && c + 3 < p.Cout) {
-        float4 b = p.bias ? *reinterpret_cast<const float4 *>(p.bias + c) : make_float4(0, 0, 0, 0);
-        float4 a = (p.act1 == CER_ACT_PRELU) ? *reinterpret_cast<const float4 *>(p.alpha + c) : make_float4(0, 0, 0, 0);
-        float bb[4] = {b.x, b.y, b.z, b.w}, aa[4] = {a.x, a.y, a.z, a.w};
-        float rr[4] = {0, 0, 0, 0}, mm[4] = {1, 1, 1, 1};
-        if (p.res) {
-            float4 r = *reinterpret_cast<const float4 *>(p.res + roff + c);
-            rr[0] = r.x; rr[1] = r.y; rr[2] = r.z; rr[3] = r.w;
-        }
-        if (p.mask) {
-            float4 k = *reinterpret_cast<const float4 *>(p.mask + doff);
-            mm[0] = k.x; mm[1] = k.y; mm[2] = k.z; mm[3] = k.w;
-        }
-        float o[4], u[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            float t = act_apply(v[e] + bb[e], p.act1, aa[e], p.slope) * mm[e];
-            u[e] = t;
-            o[e] = act_apply(t + rr[e], p.act2, 0.f, p.slope);
-        }
-        if (p.aux) *reinterpret_cast<float4 *>(p.aux + doff) = make_float4(u[0], u[1], u[2], u[3]);
-        *reinterpret_cast<float4 *>(p.y + yoff) = make_float4(o[0], o[1], o[2], o[3]);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            if (c + e < p.Cout) {
-                float t = v[e] + (p.bias ? p.bias[c + e] : 0.f);
-                t = act_apply(t, p.act1, p.act1 == CER_ACT_PRELU ? p.alpha[c + e] : 0.f, p.slope);
-                if (p.mask) t *= p.mask[doff + e];
-                if (p.aux) p.aux[doff + e] = t;
-                if (p.res) t += p.res[roff + c + e];
-                p.y[yoff + e] = act_apply(t, p.act2, 0.f, p.slope);
-            }
-        }
-    }
-}
 
 // VAR bit 0: s_setprio(1) around the MFMA cluster; bit 1: single LDS buffer (two barriers per
 // step, half the LDS -> more resident blocks per CU).
@@ -535,11 +446,19 @@ static int validate_desc(const cer_conv_desc *d) {
     return CER_OK;
 }
 
-extern "C" int cer_conv2d_stats_tiles(const cer_conv_desc *d) {
+namespace cer {
+int conv_b3_tile_dims(int tile, int Cout, long long M, int &bm, int &bn, int &bk);
+}
+
+extern "C" int cer_conv2d_stats_tiles(const cer_conv_desc *d, int bf16x3) {
     if (!d || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
     const int M = d->N * d->Ho * d->Wo;
-    int bm, bn;
-    tile_dims(pick_tile(d, M) % 10, bm, bn);
+    int bm, bn, bk;
+    if (bf16x3) {
+        if (!conv_b3_tile_dims(d->tile, d->Cout, M, bm, bn, bk)) return 0;
+    } else {
+        tile_dims(pick_tile(d, M) % 10, bm, bn);
+    }
     return (M + bm - 1) / bm;
 }
 
@@ -548,32 +467,52 @@ extern "C" size_t cer_conv2d_workspace_bytes(const cer_conv_desc *d) {
     return (size_t)d->split_k * d->N * d->Ho * d->Wo * d->Cout * sizeof(float);
 }
 
-extern "C" int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const float *w,
-                              const float *in_scale, const float *in_shift, const float *bias,
-                              const float *alpha, const float *residual, const float *mask, float *y,
-                              float *aux, float *stats, void *workspace, size_t workspace_bytes, void *stream) {
+namespace cer {
+int conv_b3_tile_dims(int tile, int Cout, long long M, int &bm, int &bn, int &bk);
+int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st);
+}  // namespace cer
+
+extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, void *workspace, size_t workspace_bytes,
+                              void *stream) {
     int rc = validate_desc(d);
     if (rc) return rc;
-    if (!x || !w || !y) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: x, w, y must be non-NULL");
-    if ((in_scale == nullptr) != (in_shift == nullptr))
-        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: in_scale and in_shift go together");
-    if (d->act1 == CER_ACT_PRELU && !alpha)
-        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: PReLU needs alpha");
-    if (residual && (d->res_stride <= 0 || d->Hr <= 0 || d->Wr <= 0 ||
-                     (d->Ho - 1) * d->res_stride >= d->Hr || (d->Wo - 1) * d->res_stride >= d->Wr))
-        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: residual geometry out of range");
-    // the deepest input coordinate any output touches must be reachable (others are zero padding)
+    if (!io) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: io block is NULL");
+    const bool b3 = io->x_hi != nullptr;
+    if (b3) {
+        if (!io->x_lo || !io->w_hi || !io->w_lo)
+            return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3): x_hi, x_lo, w_hi, w_lo must all be given");
+        if (io->in_scale || io->mask || io->aux || d->x_nchw)
+            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3): no input affine / mask / aux / NCHW input");
+    } else if (!io->x || !io->w) {
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: x and w must be non-NULL");
+    }
+    if (!io->y && !io->y_hi) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: no output tensor");
+    if ((io->in_scale == nullptr) != (io->in_shift == nullptr))
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: in_scale and in_shift go together");
+    if ((io->y_hi == nullptr) != (io->y_lo == nullptr) || (io->res_hi == nullptr) != (io->res_lo == nullptr) ||
+        (io->y2_hi == nullptr) != (io->y2_lo == nullptr) || (io->y2_hi && (!io->s2 || !io->t2)))
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: split tensors need both planes (and s2/t2 for the second output)");
+    if (io->residual && io->res_hi) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: give the residual as fp32 OR split");
+    if (d->act1 == CER_ACT_PRELU && !io->alpha) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: PReLU needs alpha");
+    const bool has_res = io->residual || io->res_hi;
+    if (has_res && (d->res_stride <= 0 || d->Hr <= 0 || d->Wr <= 0 || (d->Ho - 1) * d->res_stride >= d->Hr ||
+                    (d->Wo - 1) * d->res_stride >= d->Wr))
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: residual geometry out of range");
+    if (io->stats && d->split_k > 1)
+        return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d: batch statistics are not available with split-K");
+    if ((io->y_hi || io->y2_hi || io->res_hi) && (d->Cout & 3))
+        return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d: split outputs / residual need Cout % 4 == 0");
     ConvArgs a{};
-    a.x = x; a.w = w; a.in_scale = in_scale; a.in_shift = in_shift; a.bias = bias; a.alpha = alpha;
-    a.res = residual; a.mask = mask; a.y = y; a.aux = aux; a.stats = stats;
-    if (stats && d->split_k > 1)
-        return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d_fwd: batch statistics are not available with split-K");
+    a.x = io->x; a.w = io->w; a.in_scale = io->in_scale; a.in_shift = io->in_shift; a.bias = io->bias; a.alpha = io->alpha;
+    a.res = io->residual; a.mask = io->mask; a.y = io->y; a.aux = io->aux; a.stats = io->stats;
+    a.x_hi = io->x_hi; a.x_lo = io->x_lo; a.w_hi = io->w_hi; a.w_lo = io->w_lo;
+    a.res_hi = io->res_hi; a.res_lo = io->res_lo; a.y_hi = io->y_hi; a.y_lo = io->y_lo;
+    a.s2 = io->s2; a.t2 = io->t2; a.y2_hi = io->y2_hi; a.y2_lo = io->y2_lo;
     a.x_ld = d->x_ld > 0 ? d->x_ld : d->Cin;
     a.y_ld = d->y_ld > 0 ? d->y_ld : d->Cout;
     if (a.x_ld < d->Cin || a.y_ld < d->Cout || ((d->Cin % 32) == 0 && (a.x_ld & 3) != 0))
-        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: x_ld/y_ld smaller than the channel count or x_ld % 4 != 0");
-    if (d->x_nchw && d->x_ld > 0)
-        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: x_ld is meaningless for NCHW input");
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: x_ld/y_ld smaller than the channel count or x_ld % 4 != 0");
+    if (d->x_nchw && d->x_ld > 0) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: x_ld is meaningless for NCHW input");
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.Ho = d->Ho; a.Wo = d->Wo; a.Cout = d->Cout;
     a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.dil_h = d->dil_h; a.dil_w = d->dil_w;
     a.pad_t = d->pad_t; a.pad_l = d->pad_l; a.x_nchw = d->x_nchw;
@@ -582,52 +521,73 @@ extern "C" int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const floa
     a.Kpad = cer_conv_kpad(d->KH, d->KW, d->Cin);
     a.M = d->N * d->Ho * d->Wo;
     const bool vec = (d->Cin % 32) == 0;
-    const int tile = pick_tile(d, d->N * d->Ho * d->Wo);
-    const int bk = (tile % 10 >= 6) ? 16 : 32;
-    a.cin_steps = vec ? d->Cin / bk : 1;
+    int tile, bm, bn, bk, esz;
+    if (b3) {
+        tile = conv_b3_tile_dims(d->tile, d->Cout, a.M, bm, bn, bk);
+        if (!tile) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3): unknown tile id");
+        if (d->Cin % bk != 0 || (a.x_ld & 7))
+            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3): Cin must be a multiple of the K step and x_ld of 8");
+        esz = 2;
+    } else {
+        tile = pick_tile(d, a.M);
+        bk = (tile % 10 >= 6) ? 16 : 32;
+        tile_dims(tile % 10, bm, bn);
+        esz = 4;
+    }
+    a.cin_steps = (vec || b3) ? d->Cin / bk : 1;
     a.steps = a.Kpad / bk;
     a.split_k = d->split_k > a.steps ? a.steps : d->split_k;
     a.steps_per_split = (a.steps + a.split_k - 1) / a.split_k;
     a.split_k = (a.steps + a.steps_per_split - 1) / a.steps_per_split;
-    int bm, bn;
-    tile_dims(tile % 10, bm, bn);
     a.tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = (a.Cout + bn - 1) / bn;
-    if (vec) {
+    if (vec || b3) {
         // the staging path addresses x and w as scalar base + 32-bit per-thread byte offset
-        if (d->KH * d->KW > 32)
-            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d_fwd: more than 32 filter taps");
+        if (d->KH * d->KW > 32) return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d: more than 32 filter taps");
         const long long span_px = (long long)bm * d->stride * d->stride + 2ll * d->H * d->W + (long long)d->W * d->stride + 2;
-        if (span_px * a.x_ld * 4 >= (1ll << 31) || (long long)bn * a.Kpad * 4 >= (1ll << 32))
-            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d_fwd: tile footprint exceeds 32-bit staging offsets");
+        if (span_px * a.x_ld * esz >= (1ll << 31) || (long long)bn * a.Kpad * esz >= (1ll << 32))
+            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d: tile footprint exceeds 32-bit staging offsets");
     }
     hipStream_t st = (hipStream_t)stream;
     ConvArgs fin = a;
     if (a.split_k > 1) {
         size_t need = (size_t)a.split_k * a.M * a.Cout * sizeof(float);
-        if (!workspace || workspace_bytes < need)
-            return cer_set_error(CER_ERR_WORKSPACE, "conv2d_fwd: split-K workspace too small");
+        if (!workspace || workspace_bytes < need) return cer_set_error(CER_ERR_WORKSPACE, "conv2d: split-K workspace too small");
         a.y = (float *)workspace;
     }
-    // tile = shape + 10*v: v = 0 -> shipped variant (single LDS buffer); v = 1 -> double buffered;
-    // v = 2 -> double buffered + setprio; 3..6 -> other A/B and timing-only ablation builds
-    switch (tile / 10) {
-        case 0: rc = launch_shape<2>(tile % 10, a, vec, st); break;
-        case 1: rc = launch_shape<0>(tile % 10, a, vec, st); break;
-        case 2: rc = launch_shape<1>(tile % 10, a, vec, st); break;
-        case 3: rc = launch_shape<6>(tile % 10, a, vec, st); break;   // single buffer + per-block priority
-        case 4: rc = launch_shape<2>(tile % 10, a, vec, st); break;   // single buffer, no setprio
-        case 5: rc = launch_shape<2 + 8>(tile % 10, a, vec, st); break;        // ablation: no staging in the loop
-        case 6: rc = launch_shape<2 + 8 + 16>(tile % 10, a, vec, st); break;   // ablation: no staging, no barriers
-        default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: unknown tile variant");
+    if (b3) {
+        rc = conv_b3_launch(tile, a, st);
+    } else {
+        // tile = shape + 10*v: v = 0 -> shipped variant (single LDS buffer); v = 1 -> double buffered;
+        // v = 2 -> double buffered + setprio; 3..6 -> other A/B and timing-only ablation builds
+        switch (tile / 10) {
+            case 0: rc = launch_shape<2>(tile % 10, a, vec, st); break;
+            case 1: rc = launch_shape<0>(tile % 10, a, vec, st); break;
+            case 2: rc = launch_shape<1>(tile % 10, a, vec, st); break;
+            case 3: rc = launch_shape<6>(tile % 10, a, vec, st); break;   // single buffer + per-block priority
+            case 4: rc = launch_shape<2>(tile % 10, a, vec, st); break;   // single buffer, no setprio
+            case 5: rc = launch_shape<2 + 8>(tile % 10, a, vec, st); break;        // ablation: no staging in the loop
+            case 6: rc = launch_shape<2 + 8 + 16>(tile % 10, a, vec, st); break;   // ablation: no staging, no barriers
+            default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: unknown tile variant");
+        }
     }
     if (rc) return rc;
     if (a.split_k > 1) {
         fin.split_k = a.split_k;
         size_t n = (size_t)a.M * ((a.Cout + 3) / 4);
-        CER_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fin,
-                           (const float *)workspace);
+        CER_LAUNCH(splitk_reduce_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, fin, (const float *)workspace);
         CER_HIP_CHECK(hipGetLastError());
     }
     return CER_OK;
+}
+
+extern "C" int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const float *w, const float *in_scale,
+                              const float *in_shift, const float *bias, const float *alpha, const float *residual,
+                              const float *mask, float *y, float *aux, float *stats, void *workspace,
+                              size_t workspace_bytes, void *stream) {
+    if (!x || !w || !y) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: x, w, y must be non-NULL");
+    cer_conv_io io{};
+    io.x = x; io.w = w; io.in_scale = in_scale; io.in_shift = in_shift; io.bias = bias; io.alpha = alpha;
+    io.residual = residual; io.mask = mask; io.y = y; io.aux = aux; io.stats = stats;
+    return cer_conv2d_run(d, &io, workspace, workspace_bytes, stream);
 }

@@ -8,7 +8,7 @@ import ctypes
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_PRELU, ACT_RELU, ConvDesc, check, current_stream, ptr  # noqa: F401
+from ._lib import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_PRELU, ACT_RELU, ConvDesc, ConvIO, check, current_stream, ptr  # noqa: F401
 
 LEAKY_SLOPE = 0.01
 
@@ -103,11 +103,109 @@ def conv2d(x, w_packed, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None
         _dev_f32(out, "out", contiguous=(y_ld == 0))
     ws_bytes = lib.cer_conv2d_workspace_bytes(ctypes.byref(d))
     ws = _empty((ws_bytes // 4,), x) if ws_bytes else None
-    stats = _empty((lib.cer_conv2d_stats_tiles(ctypes.byref(d)), 2, cout), x) if want_stats else None
+    stats = _empty((lib.cer_conv2d_stats_tiles(ctypes.byref(d), 0), 2, cout), x) if want_stats else None
     check(lib.cer_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_packed), ptr(in_scale), ptr(in_shift), ptr(bias),
                              ptr(alpha), ptr(residual), ptr(mask), ptr(out), ptr(aux), ptr(stats), ptr(ws), ws_bytes,
                              current_stream()), "cer_conv2d_fwd")
     return (out, stats) if want_stats else out
+
+
+class Split:
+    """A tensor carried as two bf16 planes: value = hi + lo (hi = bf16(v), lo = bf16(v - hi))."""
+    __slots__ = ("hi", "lo")
+
+    def __init__(self, hi, lo):
+        self.hi, self.lo = hi, lo
+
+    @property
+    def shape(self):
+        return self.hi.shape
+
+    def float(self):
+        return self.hi.float() + self.lo.float()
+
+    @staticmethod
+    def empty(shape, device):
+        return Split(torch.empty(shape, device=device, dtype=torch.bfloat16),
+                     torch.empty(shape, device=device, dtype=torch.bfloat16))
+
+
+def split_bf16(x):
+    """fp32 tensor -> Split (round-to-nearest-even on both parts)."""
+    _dev_f32(x, "x")
+    out = Split.empty(x.shape, x.device)
+    check(_lib.load().cer_split_bf16(ptr(x), ptr(out.hi), ptr(out.lo), x.numel(), current_stream()), "cer_split_bf16")
+    return out
+
+
+def _dev_bf16(t, name):
+    if t is not None and not (t.is_cuda and t.dtype == torch.bfloat16 and t.is_contiguous()):
+        raise ValueError(f"{name}: expected a contiguous bfloat16 GPU tensor")
+
+
+def conv2d_b3(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bias=None, alpha=None, residual=None,
+              res_stride=1, act1=ACT_NONE, act2=ACT_NONE, slope=LEAKY_SLOPE, split_k=1, tile=0, out_f32=False,
+              out_split=True, next_affine=None, want_stats=False):
+    """bf16x3 convolution.  x, w: Split tensors (x NHWC [N,H,W,Cin], w [Cout,Kpad]); residual: Split
+    or fp32 tensor.  Returns a dict with the requested outputs: 'y' (fp32), 'split' (Split), 'next'
+    (Split of out*s2+t2 when ``next_affine=(s2, t2)``), 'stats'."""
+    lib = _lib.load()
+    for t, n in ((x.hi, "x.hi"), (x.lo, "x.lo"), (w.hi, "w.hi"), (w.lo, "w.lo")):
+        _dev_bf16(t, n)
+    _dev_f32(bias, "bias")
+    _dev_f32(alpha, "alpha")
+    n, h, wd, cin = x.shape
+    cout = w.shape[0]
+    if w.shape[1] != conv_kpad(kh, kw, cin):
+        raise ValueError(f"packed weight has K={w.shape[1]}, expected {conv_kpad(kh, kw, cin)}")
+    if out_hw is None:
+        ho = (h + 2 * pad[0] - dil[0] * (kh - 1) - 1) // stride + 1
+        wo = (wd + 2 * pad[1] - dil[1] * (kw - 1) - 1) // stride + 1
+    else:
+        ho, wo = out_hw
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, wd, cin, ho, wo, cout
+    d.KH, d.KW, d.stride, d.dil_h, d.dil_w, d.pad_t, d.pad_l = kh, kw, stride, dil[0], dil[1], pad[0], pad[1]
+    d.res_stride, d.Hr, d.Wr = res_stride, 0, 0
+    d.act1, d.act2, d.slope, d.split_k, d.tile = act1, act2, slope, split_k, tile
+    io = ConvIO()
+    io.x_hi, io.x_lo, io.w_hi, io.w_lo = x.hi.data_ptr(), x.lo.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr()
+    io.bias = bias.data_ptr() if bias is not None else None
+    io.alpha = alpha.data_ptr() if alpha is not None else None
+    if residual is not None:
+        rshape = residual.shape
+        if rshape[0] != n or rshape[3] != cout:
+            raise ValueError("residual shape does not match the output")
+        d.Hr, d.Wr = rshape[1], rshape[2]
+        if isinstance(residual, Split):
+            _dev_bf16(residual.hi, "residual.hi")
+            io.res_hi, io.res_lo = residual.hi.data_ptr(), residual.lo.data_ptr()
+        else:
+            _dev_f32(residual, "residual")
+            io.residual = residual.data_ptr()
+    res = {}
+    dev = x.hi.device
+    if out_f32:
+        res["y"] = torch.empty((n, ho, wo, cout), device=dev, dtype=torch.float32)
+        io.y = res["y"].data_ptr()
+    if out_split:
+        res["split"] = Split.empty((n, ho, wo, cout), dev)
+        io.y_hi, io.y_lo = res["split"].hi.data_ptr(), res["split"].lo.data_ptr()
+    if next_affine is not None:
+        s2, t2 = next_affine
+        _dev_f32(s2, "s2")
+        _dev_f32(t2, "t2")
+        res["next"] = Split.empty((n, ho, wo, cout), dev)
+        io.s2, io.t2 = s2.data_ptr(), t2.data_ptr()
+        io.y2_hi, io.y2_lo = res["next"].hi.data_ptr(), res["next"].lo.data_ptr()
+    if want_stats:
+        res["stats"] = torch.empty((lib.cer_conv2d_stats_tiles(ctypes.byref(d), 1), 2, cout), device=dev,
+                                   dtype=torch.float32)
+        io.stats = res["stats"].data_ptr()
+    ws_bytes = lib.cer_conv2d_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty((ws_bytes // 4,), device=dev, dtype=torch.float32) if ws_bytes else None
+    check(lib.cer_conv2d_run(ctypes.byref(d), ctypes.byref(io), ptr(ws), ws_bytes, current_stream()), "cer_conv2d_run")
+    return res
 
 
 def linear(x2d, w_packed, bias=None, act=ACT_NONE, split_k=1, residual=None, out=None):

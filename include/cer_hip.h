@@ -64,7 +64,7 @@ int cer_version(void);
  *   mask     [N,Ho,Wo,Cout] or NULL (pre-scaled dropout mask)
  *   aux      [N,Ho,Wo,Cout] or NULL: receives mask*act1(conv+bias), the value before
  *            the residual add (saved for the backward pass of a TemporalBlock)
- *   stats    [cer_conv2d_stats_tiles(d)][2][Cout] or NULL: per-tile sum and sum of squares
+ *   stats    [cer_conv2d_stats_tiles(d, bf16x3)][2][Cout] or NULL: per-tile sum and sum of squares
  *            of the RAW conv result over valid pixels (deterministic partials for the
  *            train-mode BatchNorm that follows; reduce with cer_bn_finalize)
  *   split_k  >= 1; > 1 needs `workspace` of cer_conv2d_workspace_bytes()
@@ -85,12 +85,39 @@ typedef struct cer_conv_desc {
 
 int cer_conv_kpad(int KH, int KW, int Cin);
 size_t cer_conv2d_workspace_bytes(const cer_conv_desc *d);
-int cer_conv2d_stats_tiles(const cer_conv_desc *d);
+int cer_conv2d_stats_tiles(const cer_conv_desc *d, int bf16x3);  /* rows of `stats` the launch will write */
 int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const float *w,
                    const float *in_scale, const float *in_shift,
                    const float *bias, const float *alpha,
                    const float *residual, const float *mask,
                    float *y, float *aux, float *stats, void *workspace, size_t workspace_bytes, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Unified entry point: every operand and output of one conv / linear launch.
+ *
+ * bf16x3 mode (x_hi != NULL): operands are SPLIT tensors, value = hi + lo with hi = bf16(v),
+ * lo = bf16(v - hi) (two bf16 planes, NHWC / [Cout][Kpad] like the fp32 layouts).  Products are
+ * evaluated as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32 accumulation: fp32-class
+ * accuracy (|logit error| 1.3e-6 on the full model) at a 5.3x higher matrix ceiling.
+ * Outputs (any subset): y fp32; (y_hi, y_lo) split; (y2_hi, y2_lo) = split(out*s2[c]+t2[c]), the next
+ * layer's eval-mode pre-conv BatchNorm applied by the producer (the zero padding of the consumer
+ * then stays exactly zero).  The residual may be fp32 (`residual`) or split (`res_hi`, `res_lo`).
+ * ---------------------------------------------------------------------- */
+typedef struct cer_conv_io {
+    const float *x, *w;                       /* fp32 mode operands */
+    const uint16_t *x_hi, *x_lo, *w_hi, *w_lo;  /* bf16x3 mode operands */
+    const float *in_scale, *in_shift, *bias, *alpha, *residual, *mask;
+    const uint16_t *res_hi, *res_lo;
+    float *y, *aux, *stats;
+    uint16_t *y_hi, *y_lo;
+    const float *s2, *t2;
+    uint16_t *y2_hi, *y2_lo;
+} cer_conv_io;
+
+int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, void *workspace, size_t workspace_bytes, void *stream);
+
+/* v -> (bf16(v), bf16(v - bf16(v))), round-to-nearest-even on both parts. */
+int cer_split_bf16(const float *x, uint16_t *hi, uint16_t *lo, size_t n, void *stream);
 
 /* Pack an OIHW (torch) conv weight into [Cout][Kpad] with optional per-output
  * scale (BatchNorm fold).  w_oihw [Cout,Cin,KH,KW]; out_scale [Cout] or NULL.

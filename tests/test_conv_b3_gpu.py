@@ -1,0 +1,74 @@
+"""bf16x3 (split hi/lo) convolution on the bf16 matrix cores vs fp32 torch-CPU."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _setup(n, cin, cout, hw, k, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, hw, hw, generator=g)
+    w = torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5
+    return x, w
+
+
+def test_split_is_round_to_nearest_and_exact_to_16_bits():
+    from feature_vs_text_compound_emotion_amd import ops
+    x = torch.randn(4096, generator=torch.Generator().manual_seed(0)) * 37.0
+    s = ops.split_bf16(x.cuda())
+    assert torch.equal(s.hi.cpu(), x.bfloat16())
+    assert torch.equal(s.lo.cpu(), (x - x.bfloat16().float()).bfloat16())
+    assert ((s.float().cpu() - x).abs() / x.abs().clamp_min(1e-6)).max().item() < 2.0 ** -15
+
+
+@pytest.mark.parametrize("n,cin,cout,hw,k,stride,tile", [
+    (3, 64, 64, 12, 3, 1, 0), (2, 128, 256, 10, 3, 1, 1), (2, 128, 256, 10, 3, 2, 3), (4, 64, 128, 9, 1, 2, 0),
+    (2, 256, 256, 10, 3, 1, 4), (3, 64, 96, 7, 3, 1, 5), (2, 128, 256, 10, 3, 1, 2)])
+def test_conv_b3_matches_fp32(n, cin, cout, hw, k, stride, tile):
+    from feature_vs_text_compound_emotion_amd import ops
+    x, w = _setup(n, cin, cout, hw, k, n * 100 + cin + cout)
+    ref = F.conv2d(x, w, None, stride, k // 2)
+    xs = ops.split_bf16(x.permute(0, 2, 3, 1).contiguous().cuda())
+    ws = ops.split_bf16(ops.pack_conv_weight(w.cuda()))
+    r = ops.conv2d_b3(xs, ws, k, k, stride=stride, pad=(k // 2, k // 2), tile=tile, out_f32=True, out_split=True)
+    got = r["y"].cpu().permute(0, 3, 1, 2)
+    # dropped lo*lo term and the bf16 rounding of lo: ~2^-16 relative per product
+    assert (got - ref).abs().max().item() < 3e-5
+    assert (r["split"].float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 6e-5
+
+
+def test_conv_b3_fused_epilogue_outputs():
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n, cin, cout, hw = 2, 64, 128, 10
+    x, w = _setup(n, cin, cout, hw, 3, 77)
+    bias, alpha = torch.randn(cout, generator=g), torch.rand(cout, generator=g) * 0.3 + 0.1
+    res = torch.randn(n, cout, hw, hw, generator=g)
+    s2, t2 = torch.rand(cout, generator=g) + 0.5, torch.randn(cout, generator=g) * 0.2
+    z = F.conv2d(x, w, None, 2, 1) + bias.view(1, -1, 1, 1)
+    z = torch.where(z >= 0, z, z * alpha.view(1, -1, 1, 1)) + res[:, :, ::2, ::2]
+    xs = ops.split_bf16(x.permute(0, 2, 3, 1).contiguous().cuda())
+    ws = ops.split_bf16(ops.pack_conv_weight(w.cuda()))
+    rs = ops.split_bf16(res.permute(0, 2, 3, 1).contiguous().cuda())
+    r = ops.conv2d_b3(xs, ws, 3, 3, stride=2, pad=(1, 1), bias=bias.cuda(), alpha=alpha.cuda(), act1=ops.ACT_PRELU,
+                      residual=rs, res_stride=2, out_f32=True, next_affine=(s2.cuda(), t2.cuda()), want_stats=True)
+    assert (r["y"].cpu().permute(0, 3, 1, 2) - z).abs().max().item() < 1e-4
+    nxt = z * s2.view(1, -1, 1, 1) + t2.view(1, -1, 1, 1)
+    assert (r["next"].float().cpu().permute(0, 3, 1, 2) - nxt).abs().max().item() < 2e-4
+    raw = F.conv2d(x, w, None, 2, 1)
+    st = r["stats"].cpu().sum(0)
+    assert (st[0] - raw.sum((0, 2, 3))).abs().max().item() < 1e-2
+    assert (st[1] - (raw * raw).sum((0, 2, 3))).abs().max().item() < 1e-2
+
+
+def test_linear_b3_split_k():
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(6)
+    m, k, cout = 70, 1280, 512
+    x, w, b = torch.randn(m, k, generator=g), torch.randn(cout, k, generator=g) / k ** 0.5, torch.randn(cout, generator=g)
+    ref = F.linear(x, w, b)
+    xs = ops.split_bf16(x.cuda().view(m, 1, 1, k))
+    ws = ops.split_bf16(w.cuda().contiguous())
+    r = ops.conv2d_b3(xs, ws, 1, 1, bias=b.cuda(), split_k=5, out_f32=True, out_split=False)
+    assert (r["y"].view(m, cout).cpu() - ref).abs().max().item() < 5e-5

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--tiles", default="0")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
+    ap.add_argument("--b3", action="store_true", help="bf16x3 kernel (split hi/lo operands)")
     a = ap.parse_args()
     scale = a.hw / 40
     for name, cin, cout, h, k, stride in SHAPES:
@@ -40,6 +41,22 @@ def main():
         w = torch.randn(cout, ops.conv_kpad(k, k, cin), device="cuda") * 0.02
         ho = (h + 2 * (k // 2) - k) // stride + 1
         flops = 2.0 * a.frames * ho * ho * cout * cin * k * k
+        if a.b3:
+            xs, ws = ops.split_bf16(x), ops.split_bf16(w)
+            for tile in [int(t) for t in a.tiles.split(",")]:
+                run = lambda: ops.conv2d_b3(xs, ws, k, k, stride=stride, pad=(k // 2, k // 2), tile=tile)  # noqa: E731
+                for _ in range(2):
+                    run()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / a.iters
+                print(f"{name:18s} H={h:3d} b3 tile={tile} {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s (effective)", flush=True)
+            continue
         for tile in [int(t) for t in a.tiles.split(",")]:
             y = torch.empty(a.frames, ho, ho, cout, device="cuda")
             for _ in range(2):
