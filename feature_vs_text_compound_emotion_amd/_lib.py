@@ -40,7 +40,7 @@ _SIGNATURES = {
     "cer_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "cer_conv2d_stats_tiles": (c_int, [POINTER(ConvDesc), c_int]),
     "cer_conv2d_run": (c_int, [POINTER(ConvDesc), POINTER(ConvIO), _P, c_size_t, _P]),
-    "cer_split_bf16": (c_int, [_P, _P, _P, c_size_t, _P]),
+    "cer_split_bf16": (c_int, [_P, _P, _P, c_int, _P, _P, c_size_t, _P]),
     "cer_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "cer_bn_finalize_workspace_bytes": (c_size_t, [c_int, c_int]),
     "cer_bn_finalize": (c_int, [_P, c_int, c_int, c_double, _P, _P, _P, _P, c_float, c_float, _P, _P, _P, c_size_t,

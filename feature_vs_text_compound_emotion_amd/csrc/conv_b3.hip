@@ -252,12 +252,19 @@ __global__ __launch_bounds__(256, 2) void conv_b3_kernel(ConvArgs p) {
     }
 }
 
-// v -> (bf16(v), bf16(v - bf16(v))), 4 elements per thread
-__global__ void split_bf16_kernel(const float4 *__restrict__ x, ushort4 *__restrict__ hi, ushort4 *__restrict__ lo,
-                                  size_t n4) {
+// v -> (bf16(v'), bf16(v' - bf16(v'))) with v' = v*scale[c] + shift[c] (channels-last, optional),
+// 4 elements per thread
+__global__ void split_bf16_kernel(const float4 *__restrict__ x, const float *__restrict__ scale,
+                                  const float *__restrict__ shift, ushort4 *__restrict__ hi, ushort4 *__restrict__ lo,
+                                  size_t n4, int C4) {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
-    const float4 v = x[i];
+    float4 v = x[i];
+    if (scale) {
+        const int c = (int)(i % C4) * 4;
+        const float4 s = *reinterpret_cast<const float4 *>(scale + c), t = *reinterpret_cast<const float4 *>(shift + c);
+        v = make_float4(v.x * s.x + t.x, v.y * s.y + t.y, v.z * s.z + t.z, v.w * s.w + t.w);
+    }
     ushort4 h, l;
     split_bf16(v.x, h.x, l.x); split_bf16(v.y, h.y, l.y);
     split_bf16(v.z, h.z, l.z); split_bf16(v.w, h.w, l.w);
@@ -304,10 +311,13 @@ int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st) {
 
 using namespace cer;
 
-extern "C" int cer_split_bf16(const float *x, uint16_t *hi, uint16_t *lo, size_t n, void *stream) {
+extern "C" int cer_split_bf16(const float *x, const float *scale, const float *shift, int C, uint16_t *hi, uint16_t *lo,
+                              size_t n, void *stream) {
     if (!x || !hi || !lo || n == 0 || (n & 3)) return cer_set_error(CER_ERR_INVALID_ARG, "split_bf16: n must be a positive multiple of 4");
-    CER_LAUNCH(split_bf16_kernel, dim3(cer_blocks(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)x,
-               (ushort4 *)hi, (ushort4 *)lo, n / 4);
+    if ((scale == nullptr) != (shift == nullptr) || (scale && (C <= 0 || (C & 3) || n % C)))
+        return cer_set_error(CER_ERR_INVALID_ARG, "split_bf16: the per-channel affine needs scale, shift and C % 4 == 0 dividing n");
+    CER_LAUNCH(split_bf16_kernel, dim3(cer_blocks(n / 4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)x, scale,
+               shift, (ushort4 *)hi, (ushort4 *)lo, n / 4, scale ? C / 4 : 1);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }

@@ -486,7 +486,7 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
     } else if (!io->x || !io->w) {
         return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: x and w must be non-NULL");
     }
-    if (!io->y && !io->y_hi) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: no output tensor");
+    if (!io->y && !io->y_hi && !io->y2_hi) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: no output tensor");
     if ((io->in_scale == nullptr) != (io->in_shift == nullptr))
         return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: in_scale and in_shift go together");
     if ((io->y_hi == nullptr) != (io->y_lo == nullptr) || (io->res_hi == nullptr) != (io->res_lo == nullptr) ||

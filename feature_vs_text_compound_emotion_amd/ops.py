@@ -54,7 +54,7 @@ def pack_conv_weight(w_oihw, out_scale=None, flip=False, transpose=False):
 def conv2d(x, w_packed, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, in_scale=None,
            in_shift=None, bias=None, alpha=None, residual=None, res_stride=1, mask=None, act1=ACT_NONE,
            act2=ACT_NONE, slope=LEAKY_SLOPE, split_k=1, x_nchw=False, tile=0, out=None, aux=None, x_ld=0, y_ld=0,
-           x_shape=None, want_stats=False):
+           x_shape=None, want_stats=False, out_split=False, next_affine=None, want_f32=True):
     """y[N,Ho,Wo,Cout] = act2(mask*act1(conv(affine(x), w)+bias) + residual).  x is NHWC
     (or NCHW with ``x_nchw`` on the small-Cin path).  ``x_shape`` = (N,H,W,Cin) overrides
     x.shape when x is a column slice (then ``x_ld`` is its row pitch)."""
@@ -95,19 +95,38 @@ def conv2d(x, w_packed, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None
         if t is not None and t.numel() != n * ho * wo * cout:
             raise ValueError(f"{nme} must have the output's shape")
     d.act1, d.act2, d.slope, d.split_k, d.tile = act1, act2, slope, split_k, tile
-    if out is None:
+    if out is None and want_f32:
         if y_ld:
             raise ValueError("y_ld needs an explicit out buffer")
         out = _empty((n, ho, wo, cout), x)
-    else:
+    elif out is not None:
         _dev_f32(out, "out", contiguous=(y_ld == 0))
     ws_bytes = lib.cer_conv2d_workspace_bytes(ctypes.byref(d))
     ws = _empty((ws_bytes // 4,), x) if ws_bytes else None
     stats = _empty((lib.cer_conv2d_stats_tiles(ctypes.byref(d), 0), 2, cout), x) if want_stats else None
-    check(lib.cer_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_packed), ptr(in_scale), ptr(in_shift), ptr(bias),
-                             ptr(alpha), ptr(residual), ptr(mask), ptr(out), ptr(aux), ptr(stats), ptr(ws), ws_bytes,
-                             current_stream()), "cer_conv2d_fwd")
-    return (out, stats) if want_stats else out
+    if not (out_split or next_affine is not None):
+        check(lib.cer_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_packed), ptr(in_scale), ptr(in_shift), ptr(bias),
+                                 ptr(alpha), ptr(residual), ptr(mask), ptr(out), ptr(aux), ptr(stats), ptr(ws), ws_bytes,
+                                 current_stream()), "cer_conv2d_fwd")
+        return (out, stats) if want_stats else out
+    # fp32 kernel with split (bf16 hi/lo) outputs: feeds the bf16x3 layers (e.g. the Cin = 3 stem)
+    io = ConvIO()
+    io.x, io.w = x.data_ptr(), w_packed.data_ptr()
+    for name, t in (("in_scale", in_scale), ("in_shift", in_shift), ("bias", bias), ("alpha", alpha),
+                    ("residual", residual), ("mask", mask), ("y", out), ("aux", aux), ("stats", stats)):
+        if t is not None:
+            setattr(io, name, t.data_ptr())
+    res = {"y": out, "stats": stats}
+    if out_split:
+        res["split"] = Split.empty((n, ho, wo, cout), x.device)
+        io.y_hi, io.y_lo = res["split"].hi.data_ptr(), res["split"].lo.data_ptr()
+    if next_affine is not None:
+        s2, t2 = next_affine
+        res["next"] = Split.empty((n, ho, wo, cout), x.device)
+        io.s2, io.t2 = s2.data_ptr(), t2.data_ptr()
+        io.y2_hi, io.y2_lo = res["next"].hi.data_ptr(), res["next"].lo.data_ptr()
+    check(lib.cer_conv2d_run(ctypes.byref(d), ctypes.byref(io), ptr(ws), ws_bytes, current_stream()), "cer_conv2d_run")
+    return res
 
 
 class Split:
@@ -124,17 +143,25 @@ class Split:
     def float(self):
         return self.hi.float() + self.lo.float()
 
+    def view(self, *shape):
+        return Split(self.hi.view(*shape), self.lo.view(*shape))
+
     @staticmethod
     def empty(shape, device):
         return Split(torch.empty(shape, device=device, dtype=torch.bfloat16),
                      torch.empty(shape, device=device, dtype=torch.bfloat16))
 
 
-def split_bf16(x):
-    """fp32 tensor -> Split (round-to-nearest-even on both parts)."""
+def split_bf16(x, scale=None, shift=None):
+    """fp32 tensor -> Split (round-to-nearest-even on both parts), optionally after the per-channel
+    affine x*scale[c]+shift[c] over the last (channel) axis."""
     _dev_f32(x, "x")
+    _dev_f32(scale, "scale")
+    _dev_f32(shift, "shift")
     out = Split.empty(x.shape, x.device)
-    check(_lib.load().cer_split_bf16(ptr(x), ptr(out.hi), ptr(out.lo), x.numel(), current_stream()), "cer_split_bf16")
+    c = x.shape[-1] if scale is not None else 0
+    check(_lib.load().cer_split_bf16(ptr(x), ptr(scale), ptr(shift), c, ptr(out.hi), ptr(out.lo), x.numel(),
+                                     current_stream()), "cer_split_bf16")
     return out
 
 

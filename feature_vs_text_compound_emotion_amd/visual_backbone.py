@@ -61,19 +61,29 @@ class IR50(nn.Module):
         self._packed_train = None
         self._packed_train_key = None
         self.bn_mode = "reference"  # or "frozen": encoder BatchNorm/Dropout stay in eval behaviour under train()
+        # "bf16x3": split hi/lo bf16 operands, 3 bf16 MFMAs per product (fp32-class accuracy, logit error
+        # ~1e-6, 2-2.5x faster); "fp32": the exact-fp32 MFMA kernels
+        self.precision = "bf16x3"
+        self._packed_b3 = None
+        self._packed_b3_key = None
+        self._packed_train_b3 = None
+        self._packed_train_b3_key = None
         self.dropout_seed = 0
         self._dropout_calls = 0
 
     def __deepcopy__(self, memo):
         """trainer.py:656,705 deep-copies the model: copy parameters/buffers, not the packed caches."""
-        caches = (self._packed, self._packed_train)
-        self._packed = self._packed_train = None
+        names = ("_packed", "_packed_train", "_packed_b3", "_packed_train_b3")
+        caches = [getattr(self, n) for n in names]
+        for n in names:
+            setattr(self, n, None)
         try:
             new = self.__class__.__new__(self.__class__)
             memo[id(self)] = new
             new.__dict__ = copy.deepcopy(self.__dict__, memo)
         finally:
-            self._packed, self._packed_train = caches
+            for n, c in zip(names, caches):
+                setattr(self, n, c)
         return new
 
     # ------------------------------------------------------------------ packing
@@ -148,6 +158,142 @@ class IR50(nn.Module):
         self._packed_train, self._packed_train_key = P, key
         return P
 
+    # ------------------------------------------------------------------ bf16x3 packing
+    def pack_b3(self):
+        """Eval-mode layouts for the bf16x3 kernels: weights as split (hi/lo bf16) planes with the post-conv
+        BatchNorms folded; every pre-conv BatchNorm becomes the PRODUCER's second output (next_affine)."""
+        key = self._state_key()
+        if self._packed_b3 is not None and key == self._packed_b3_key:
+            return self._packed_b3
+        if self.input_layer[0].weight.device.type != "cuda":
+            raise RuntimeError("IR50 runs on the HIP kernels only: move the module to a GPU (no CPU fallback)")
+        P = {}
+        s, b = self._bn_affine(self.input_layer[1])
+        P["stem_w"] = ops.pack_conv_weight(self.input_layer[0].weight.detach().contiguous(), s)
+        P["stem_b"], P["stem_a"] = b, self.input_layer[2].weight.detach().contiguous()
+        units = []
+        for u in self.body:
+            d = {"stride": u.stride, "proj": u.cin != u.depth}
+            d["in_s"], d["in_b"] = self._bn_affine(u.res_layer[0])
+            d["w1"] = ops.split_bf16(ops.pack_conv_weight(u.res_layer[1].weight.detach().contiguous()))
+            d["a1"] = u.res_layer[2].weight.detach().contiguous()
+            s2, b2 = self._bn_affine(u.res_layer[4])
+            d["w2"] = ops.split_bf16(ops.pack_conv_weight(u.res_layer[3].weight.detach().contiguous(), s2))
+            d["b2"] = b2
+            if d["proj"]:
+                ss, sb = self._bn_affine(u.shortcut_layer[1])
+                d["ws"] = ops.split_bf16(ops.pack_conv_weight(u.shortcut_layer[0].weight.detach().contiguous(), ss))
+                d["bs"] = sb
+            units.append(d)
+        P["units"] = units
+        hw = self.head_hw
+        P["head_in"] = self._bn_affine(self.output_layer[0])
+        s4, t4 = self._bn_affine(self.output_layer[4])
+        fc = self.output_layer[3]
+        w = fc.weight.detach().view(fc.out_features, -1, hw * hw).permute(0, 2, 1).contiguous().view(fc.out_features, -1)
+        P["head_w"] = ops.split_bf16((w * s4.view(-1, 1)).contiguous())
+        P["head_b"] = (fc.bias.detach() * s4 + t4).contiguous()
+        self._packed_b3, self._packed_b3_key = P, key
+        return P
+
+    def pack_train_b3(self):
+        key = tuple((p.data_ptr(), p._version) for p in self.parameters())
+        if self._packed_train_b3 is not None and key == self._packed_train_b3_key:
+            return self._packed_train_b3
+        if self.input_layer[0].weight.device.type != "cuda":
+            raise RuntimeError("IR50 runs on the HIP kernels only: move the module to a GPU (no CPU fallback)")
+        P = {"stem_w": ops.pack_conv_weight(self.input_layer[0].weight.detach().contiguous()), "units": []}
+        for u in self.body:
+            d = {"w1": ops.split_bf16(ops.pack_conv_weight(u.res_layer[1].weight.detach().contiguous())),
+                 "w2": ops.split_bf16(ops.pack_conv_weight(u.res_layer[3].weight.detach().contiguous()))}
+            if u.cin != u.depth:
+                d["ws"] = ops.split_bf16(ops.pack_conv_weight(u.shortcut_layer[0].weight.detach().contiguous()))
+            P["units"].append(d)
+        fc, hw = self.output_layer[3], self.head_hw
+        P["head_w"] = ops.split_bf16(fc.weight.detach().view(fc.out_features, -1, hw * hw).permute(0, 2, 1).contiguous().view(
+            fc.out_features, -1))
+        self._packed_train_b3, self._packed_train_b3_key = P, key
+        return P
+
+    def _forward_b3(self, x):
+        """Eval / frozen forward on the bf16x3 kernels (Cin = 3 stem on the fp32 small-Cin kernel)."""
+        P = self.pack_b3()
+        U = P["units"]
+        r = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), bias=P["stem_b"], alpha=P["stem_a"],
+                       act1=ops.ACT_PRELU, x_nchw=True, want_f32=False, out_split=True,
+                       next_affine=(U[0]["in_s"], U[0]["in_b"]))
+        x_raw, x_bn = r["split"], r["next"]
+        for i, d in enumerate(U):
+            s = d["stride"]
+            t = ops.conv2d_b3(x_bn, d["w1"], 3, 3, pad=(1, 1), alpha=d["a1"], act1=ops.ACT_PRELU)["split"]
+            last = i + 1 == len(U)
+            nxt = P["head_in"] if last else (U[i + 1]["in_s"], U[i + 1]["in_b"])
+            if d["proj"]:
+                sc = ops.conv2d_b3(x_raw, d["ws"], 1, 1, stride=s, bias=d["bs"])["split"]
+                r = ops.conv2d_b3(t, d["w2"], 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=sc, res_stride=1,
+                                  out_split=not last, next_affine=nxt)
+            else:
+                r = ops.conv2d_b3(t, d["w2"], 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=x_raw, res_stride=s,
+                                  out_split=not last, next_affine=nxt)
+            x_raw, x_bn = r.get("split"), r["next"]
+        n, h, w, c = x_bn.shape
+        if h != self.head_hw or w != self.head_hw:
+            raise RuntimeError(f"IR50 head was built for {self.head_hw}x{self.head_hw} feature maps "
+                               f"({8 * self.head_hw}x{8 * self.head_hw} frames) but got {h}x{w}")
+        k = h * w * c
+        e = ops.conv2d_b3(x_bn.view(n, 1, 1, k), P["head_w"], 1, 1, bias=P["head_b"], split_k=self._head_split_k(n, k),
+                          out_f32=True, out_split=False)["y"]
+        return ops.l2norm_rows(e.view(n, -1))
+
+    def _forward_batch_stats_b3(self, x, head_mask=None):
+        """Reference train() semantics (batch-statistics BatchNorm everywhere) with the convolutions on the
+        bf16x3 kernels.  Statistics and normalisation stay fp32; conv inputs are re-split after each
+        BatchNorm because its scale/shift only exist once the whole batch has been reduced."""
+        P = self.pack_train_b3()
+        self._packed = self._packed_b3 = None  # running statistics are about to change
+        n = x.shape[0]
+        y0, st = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True)
+        s, t = self._finalize(st, y0.numel() // 64, self.input_layer[1])
+        y, xst = ops.bn_apply_nhwc(y0, s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True)
+        del y0
+        for u, d in zip(self.body, P["units"]):
+            s1, t1 = self._finalize(xst, y.numel() // u.cin, u.res_layer[0])
+            tt = ops.conv2d_b3(ops.split_bf16(y, s1, t1), d["w1"], 3, 3, pad=(1, 1), alpha=u.res_layer[2].weight.detach(),
+                               act1=ops.ACT_PRELU)["split"]
+            r = ops.conv2d_b3(tt, d["w2"], 3, 3, stride=u.stride, pad=(1, 1), out_f32=True, out_split=False,
+                              want_stats=True)
+            del tt
+            z = r["y"]
+            cnt = z.numel() // u.depth
+            s2, t2 = self._finalize(r["stats"], cnt, u.res_layer[4])
+            if u.cin != u.depth:
+                rs = ops.conv2d_b3(ops.split_bf16(y), d["ws"], 1, 1, stride=u.stride, out_f32=True, out_split=False,
+                                   want_stats=True)
+                ss, stt = self._finalize(rs["stats"], cnt, u.shortcut_layer[1])
+                y, xst = ops.bn_apply_nhwc(z, s2, t2, res=rs["y"], res_scale=ss, res_shift=stt, want_stats=True)
+            else:
+                y, xst = ops.bn_apply_nhwc(z, s2, t2, res=y, res_stride=u.stride, want_stats=True)
+            del z, r
+        nn_, h, w, c = y.shape
+        if h != self.head_hw or w != self.head_hw:
+            raise RuntimeError(f"IR50 head was built for {self.head_hw}x{self.head_hw} feature maps but got {h}x{w}")
+        s0, t0 = self._finalize(xst, y.numel() // c, self.output_layer[0])
+        p_drop = self.output_layer[1].p
+        if head_mask is None and p_drop > 0:
+            self._dropout_calls += 1
+            head_mask = ops.dropout_mask(tuple(y.shape), p_drop, 0x1f50 + self.dropout_seed, self._dropout_calls * y.numel(),
+                                         y.device)
+        hfeat = ops.bn_apply_nhwc(y, s0, t0, mask=head_mask)
+        k = h * w * c
+        fc, bn1 = self.output_layer[3], self.output_layer[4]
+        e = ops.conv2d_b3(ops.split_bf16(hfeat).view(n, 1, 1, k), P["head_w"], 1, 1, bias=fc.bias.detach(),
+                          split_k=self._head_split_k(n, k), out_f32=True, out_split=False)["y"].view(n, -1)
+        e, _, _ = ops.bn_rows_fwd(e, bn1.weight.detach(), bn1.bias.detach(), bn1.running_mean, bn1.running_var, True,
+                                  bn1.eps, bn1.momentum)
+        torch._foreach_add_([m.num_batches_tracked for m in self.modules()
+                             if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d))], 1)
+        return ops.l2norm_rows(e)
+
     # ------------------------------------------------------------------ forward
     def _head_split_k(self, n, k):
         tiles = ((n + 127) // 128) * 4
@@ -162,7 +308,7 @@ class IR50(nn.Module):
         updates its running buffers; Dropout(0.4) before the head FC.  ``head_mask`` ([N,h,w,512],
         pre-scaled) overrides the generated dropout mask (parity tests)."""
         P = self.pack_train()
-        self._packed = None  # running statistics are about to change: the folded eval weights go stale
+        self._packed = self._packed_b3 = None  # running statistics are about to change: folded eval weights go stale
         n = x.shape[0]
         y0, st = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True)
         s, t = self._finalize(st, y0.numel() // 64, self.input_layer[1])
@@ -209,8 +355,14 @@ class IR50(nn.Module):
         train(): ``bn_mode == "reference"`` reproduces the reference, whose model.train() also puts
         this frozen encoder's BatchNorm/Dropout layers in train mode (SURVEY.md F6);
         ``bn_mode == "frozen"`` keeps the encoder in eval behaviour (common practice, faster)."""
+        if self.precision not in ("bf16x3", "fp32"):
+            raise ValueError(f"unknown precision {self.precision!r}")
         if self.training and self.bn_mode == "reference":
+            if self.precision == "bf16x3":
+                return self._forward_batch_stats_b3(x, head_mask)
             return self._forward_batch_stats(x, head_mask)
+        if self.precision == "bf16x3":
+            return self._forward_b3(x)
         P = self.pack()
         x = x.contiguous()
         y = ops.conv2d(x, P["stem_w"], 3, 3, pad=(1, 1), bias=P["stem_b"], alpha=P["stem_a"],

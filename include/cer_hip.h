@@ -116,8 +116,10 @@ typedef struct cer_conv_io {
 
 int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, void *workspace, size_t workspace_bytes, void *stream);
 
-/* v -> (bf16(v), bf16(v - bf16(v))), round-to-nearest-even on both parts. */
-int cer_split_bf16(const float *x, uint16_t *hi, uint16_t *lo, size_t n, void *stream);
+/* v' = v*scale[c]+shift[c] (channels-last, C channels; scale/shift may be NULL) -> (bf16(v'), bf16(v' - bf16(v'))),
+ * round-to-nearest-even on both parts. */
+int cer_split_bf16(const float *x, const float *scale, const float *shift, int C, uint16_t *hi, uint16_t *lo, size_t n,
+                   void *stream);
 
 /* Pack an OIHW (torch) conv weight into [Cout][Kpad] with optional per-output
  * scale (BatchNorm fold).  w_oihw [Cout,Cin,KH,KW]; out_scale [Cout] or NULL.
