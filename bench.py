@@ -24,6 +24,7 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak; the bf16x3 kernels spend 3 MFMAs per product -> 833.3 effective
 MODS = ["video", "vggish", "bert"]
 
 
@@ -54,12 +55,12 @@ def build_model(hw, length, device):
     return model.to(device), sd
 
 
-def measured_traffic(hw, batch, length, encoders):
+def measured_traffic(hw, batch, length, encoders, precision):
     """HBM bytes per step of cer::conv_igemm_kernel from the committed rocprofv3 PMC passes
     (tools/collect_traffic.py: FETCH_SIZE x2 + WRITE_SIZE, separate passes, gfx950 corrections).  PMC
     counters cannot be read from inside the timed process, so the value is looked up by configuration
     and is null when no profile of this exact configuration has been committed."""
-    path = os.path.join(ROOT, "profiles", f"round1_traffic_hw{hw}.json")
+    path = os.path.join(ROOT, "profiles", f"round1_traffic_{precision}_hw{hw}.json")
     try:
         t = json.load(open(path))
     except (OSError, ValueError):
@@ -169,6 +170,9 @@ def main():
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--length", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
+                    help="IR-50 conv kernels: bf16x3 = split hi/lo bf16 operands, 3 bf16 MFMAs per product, fp32-class "
+                         "accuracy (logit error ~1e-6); fp32 = exact fp32 MFMA")
     ap.add_argument("--encoders", choices=["on", "off"], default="on",
                     help="on: VGGish (log-mel from 1 s PCM) and BERT (64 tokens) run on the GPU inside the step; "
                          "off: pre-computed per-frame features, as the reference trainer feeds them")
@@ -187,6 +191,7 @@ def main():
     dev = torch.device("cuda", local)
 
     model, _ = build_model(a.hw, a.length, dev)
+    model.spatial["visual"].backbone.precision = a.precision
     model.train()
     ddp = ClipDataParallel(model, world_size=world)
     opt = torch.optim.SGD(params=ddp.params, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=True)  # lr 1e-3 (F8)
@@ -247,6 +252,8 @@ def main():
     frames = a.batch * a.length
     flops = ir50_forward_flops(a.hw) * frames
     achieved = flops / (enc_ms * 1e-3) / 1e12
+    b3 = a.precision == "bf16x3"
+    peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if b3 else FP32_MFMA_PEAK_TFLOPS
 
     if rank == 0:
         res = {
@@ -256,7 +263,8 @@ def main():
             "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": dt / a.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic",
+            "dtype": "bf16x3 (split hi/lo bf16 operands, fp32 accumulate; fp32-class accuracy)" if b3 else "f32",
+            "data": "synthetic",
             "config": {"workload": f"LFAN tri-modal training step: frozen IR-50 forward on {a.batch}x{a.length} frames "
                                    f"of {a.hw}x{a.hw} + TCN/fusion/regressor forward+backward + CE + Nesterov SGD; "
                                    + ("VGGish (log-mel of 1 s PCM, 32 examples/clip) and BERT-base (64-token sentence) run on "
@@ -264,13 +272,18 @@ def main():
                                       "vggish/bert as pre-computed per-frame features (as the reference trainer feeds them)"),
                        "encoders_on_gpu": a.encoders == "on",
                        "clips_per_gpu": a.batch, "global_batch": a.batch * world, "frames_per_clip": a.length,
-                       "frame_hw": a.hw, "n_classes": 7, "parallelism": f"dp{world} over clips, flat-bucket RCCL all-reduce",
+                       "frame_hw": a.hw, "n_classes": 7, "conv_precision": a.precision, "parallelism": f"dp{world} over clips, flat-bucket RCCL all-reduce",
                        "loss": float(loss.item())},
-            "roofline": {"bound": "mfma", "kernel": "cer::conv_igemm_kernel (IR-50 forward: 52 implicit-GEMM convs + head FC, "
-                                                    "v_mfma_f32_32x32x2_f32)",
-                         "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
-                         "traffic": measured_traffic(a.hw, a.batch, a.length, a.encoders),
+            "roofline": {"bound": "mfma",
+                         "kernel": ("cer::conv_b3_kernel (IR-50 forward: 51 implicit-GEMM convs + head FC on "
+                                    "v_mfma_f32_32x32x16_bf16, 3 MFMAs per product; stem on the fp32 kernel; span includes the "
+                                    "batch-statistics BatchNorm passes)" if b3 else
+                                    "cer::conv_igemm_kernel (IR-50 forward: 52 implicit-GEMM convs + head FC, "
+                                    "v_mfma_f32_32x32x2_f32)"),
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 3 products per multiply" if b3 else
+                                       "fp32 MFMA peak"),
+                         "traffic": measured_traffic(a.hw, a.batch, a.length, a.encoders, a.precision),
                          "traffic_note": "HBM bytes per step over all conv_igemm launches (rocprofv3 PMC, "
                                          "profiles/round1_traffic_hw*.json); algorithmic minimum is "
                                          "18.6 MB/frame @40x40, 584 MB/frame @224x224 (SURVEY 8d)",

@@ -455,7 +455,9 @@ extern "C" int cer_conv2d_stats_tiles(const cer_conv_desc *d, int bf16x3) {
     const int M = d->N * d->Ho * d->Wo;
     int bm, bn, bk;
     if (bf16x3) {
-        if (!conv_b3_tile_dims(d->tile, d->Cout, M, bm, bn, bk)) return 0;
+        const int t = conv_b3_tile_dims(d->tile, d->Cout, M, bm, bn, bk);
+        if (!t) return 0;
+        if (t == 6) return 2 * ((M + bm - 1) / bm);  // the ping-pong kernel writes one row per pixel half-tile
     } else {
         tile_dims(pick_tile(d, M) % 10, bm, bn);
     }

@@ -28,17 +28,24 @@ __global__ void bn_partial_reduce_kernel(const float *__restrict__ partials, int
     }
 }
 
+// One wave per channel: lanes fold the group rows, then a double-precision wave reduction.
 __global__ void bn_finalize_kernel(const double *__restrict__ groups, int ngroups, int C, double count,
                                    const float *__restrict__ gamma, const float *__restrict__ beta,
                                    float *__restrict__ running_mean, float *__restrict__ running_var,
                                    float momentum, float eps, float *__restrict__ scale, float *__restrict__ shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    const int c = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (c >= C) return;
     double s1 = 0.0, s2 = 0.0;
-    for (int t = 0; t < ngroups; ++t) {
+    for (int t = lane; t < ngroups; t += 64) {
         s1 += groups[((size_t)t * 2 + 0) * C + c];
         s2 += groups[((size_t)t * 2 + 1) * C + c];
     }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        s1 += __shfl_xor(s1, o);
+        s2 += __shfl_xor(s2, o);
+    }
+    if (lane != 0) return;
     const double mean = s1 / count;
     double var = s2 / count - mean * mean;
     if (var < 0.0) var = 0.0;
@@ -159,7 +166,7 @@ extern "C" int cer_bn_finalize(const float *partials, int tiles, int C, double c
     const int used = (tiles + rows_per_group - 1) / rows_per_group;
     CER_LAUNCH(bn_partial_reduce_kernel, dim3(used), dim3(256), 0, (hipStream_t)stream, partials, tiles, C,
                rows_per_group, (double *)workspace);
-    CER_LAUNCH(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)stream, (const double *)workspace,
+    CER_LAUNCH(bn_finalize_kernel, dim3((C + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const double *)workspace,
                used, C, count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;

@@ -24,7 +24,8 @@ def test_split_is_round_to_nearest_and_exact_to_16_bits():
 
 @pytest.mark.parametrize("n,cin,cout,hw,k,stride,tile", [
     (3, 64, 64, 12, 3, 1, 0), (2, 128, 256, 10, 3, 1, 1), (2, 128, 256, 10, 3, 2, 3), (4, 64, 128, 9, 1, 2, 0),
-    (2, 256, 256, 10, 3, 1, 4), (3, 64, 96, 7, 3, 1, 5), (2, 128, 256, 10, 3, 1, 2)])
+    (2, 256, 256, 10, 3, 1, 4), (3, 64, 96, 7, 3, 1, 5), (2, 128, 256, 10, 3, 1, 2), (2, 128, 256, 10, 3, 1, 6),
+    (5, 64, 128, 9, 3, 2, 6), (3, 96, 100, 7, 3, 1, 6)])
 def test_conv_b3_matches_fp32(n, cin, cout, hw, k, stride, tile):
     from feature_vs_text_compound_emotion_amd import ops
     x, w = _setup(n, cin, cout, hw, k, n * 100 + cin + cout)
@@ -38,7 +39,8 @@ def test_conv_b3_matches_fp32(n, cin, cout, hw, k, stride, tile):
     assert (r["split"].float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 6e-5
 
 
-def test_conv_b3_fused_epilogue_outputs():
+@pytest.mark.parametrize("tile", [0, 6])
+def test_conv_b3_fused_epilogue_outputs(tile):
     from feature_vs_text_compound_emotion_amd import ops
     g = torch.Generator().manual_seed(5)
     n, cin, cout, hw = 2, 64, 128, 10
@@ -52,7 +54,7 @@ def test_conv_b3_fused_epilogue_outputs():
     ws = ops.split_bf16(ops.pack_conv_weight(w.cuda()))
     rs = ops.split_bf16(res.permute(0, 2, 3, 1).contiguous().cuda())
     r = ops.conv2d_b3(xs, ws, 3, 3, stride=2, pad=(1, 1), bias=bias.cuda(), alpha=alpha.cuda(), act1=ops.ACT_PRELU,
-                      residual=rs, res_stride=2, out_f32=True, next_affine=(s2.cuda(), t2.cuda()), want_stats=True)
+                      residual=rs, res_stride=2, out_f32=True, next_affine=(s2.cuda(), t2.cuda()), want_stats=True, tile=tile)
     assert (r["y"].cpu().permute(0, 3, 1, 2) - z).abs().max().item() < 1e-4
     nxt = z * s2.view(1, -1, 1, 1) + t2.view(1, -1, 1, 1)
     assert (r["next"].float().cpu().permute(0, 3, 1, 2) - nxt).abs().max().item() < 2e-4
@@ -70,5 +72,6 @@ def test_linear_b3_split_k():
     ref = F.linear(x, w, b)
     xs = ops.split_bf16(x.cuda().view(m, 1, 1, k))
     ws = ops.split_bf16(w.cuda().contiguous())
-    r = ops.conv2d_b3(xs, ws, 1, 1, bias=b.cuda(), split_k=5, out_f32=True, out_split=False)
-    assert (r["y"].view(m, cout).cpu() - ref).abs().max().item() < 5e-5
+    for tile in (0, 6):
+        r = ops.conv2d_b3(xs, ws, 1, 1, bias=b.cuda(), split_k=5, out_f32=True, out_split=False, tile=tile)
+        assert (r["y"].view(m, cout).cpu() - ref).abs().max().item() < 5e-5
