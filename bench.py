@@ -111,7 +111,7 @@ def cpu_baseline(hw, length, encoders=True):
     alias = synth.lfan_spec(MODS, head_hw=hw // 8)[1]
     names = [k for k in sd if not k.startswith("spatial.") and k not in alias
              and not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
-    clips, steps = (4, 1) if hw <= 64 else (1, 1)
+    clips, steps = (8, 3) if hw <= 64 else (1, 1)  # ~10-15 s of CPU work either way
 
     if encoders:
         import oracle
@@ -284,9 +284,11 @@ def main():
                          "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 3 products per multiply" if b3 else
                                        "fp32 MFMA peak"),
                          "traffic": measured_traffic(a.hw, a.batch, a.length, a.encoders, a.precision),
-                         "traffic_note": "HBM bytes per step over all conv_igemm launches (rocprofv3 PMC, "
-                                         "profiles/round1_traffic_hw*.json); algorithmic minimum is "
-                                         "18.6 MB/frame @40x40, 584 MB/frame @224x224 (SURVEY 8d)",
+                         "traffic_note": "HBM bytes per step over all conv kernel launches (rocprofv3 PMC passes, "
+                                         "profiles/round1_traffic_<precision>_hw*.json: FETCH_SIZE x2 + WRITE_SIZE; the x2 "
+                                         "read correction is calibrated for 128-B requests and may over-count the bf16x3 "
+                                         "kernel's 64-B row segments); algorithmic minimum 18.6 MB/frame @40x40, "
+                                         "584 MB/frame @224x224 (SURVEY 8d)",
                          "algorithmic_flops_per_step": flops, "ms_per_step_in_kernel": enc_ms},
         }
         if world == 1 and not a.no_cpu_baseline:
