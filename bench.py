@@ -182,7 +182,11 @@ def main():
     from feature_vs_text_compound_emotion_amd.data_parallel import ClipDataParallel, init_process_group_from_env
     from feature_vs_text_compound_emotion_amd.lfan import cross_entropy_loss
 
-    rank, world, local = init_process_group_from_env()
+    # CER_BENCH_BACKEND=gloo rehearses the N>1 path on a one-GPU box (all ranks share cuda:0); the driver's
+    # real multi-GPU runs use the default: RCCL ("nccl"), one rank per GPU
+    rank, world, local = init_process_group_from_env(os.environ.get("CER_BENCH_BACKEND"))
+    if os.environ.get("CER_BENCH_BACKEND") == "gloo" and torch.cuda.is_available():
+        local = local % torch.cuda.device_count()
     if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     if not torch.cuda.is_available():
