@@ -171,3 +171,28 @@ def test_attention_backward_vs_torch_autograd(b, h, sq, sk, d):
     assert (out.cpu() - ref.detach()).abs().max().item() < 2e-5
     for got, want in ((dq, q.grad), (dk, k.grad), (dv, v.grad)):
         assert (got.cpu() - want).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("nb,tokens", [(6, 320), (8, 40), (2, 24)])
+def test_attention_fwd_bwd_on_fused_qkv_buffer_with_interleaved_batches(nb, tokens):
+    """JMT's final stage: rows = token*nb + slot in one [R, 3E] buffer (batch stride 1 row, token stride nb rows)."""
+    from feature_vs_text_compound_emotion_amd import ops
+    E = 128
+    g = torch.Generator().manual_seed(nb * 1000 + tokens)
+    qkv = torch.randn(tokens * nb, 3 * E, generator=g, requires_grad=True)
+    x = qkv.view(tokens, nb, 3, E)
+    q, k, v = x[:, :, 0], x[:, :, 1], x[:, :, 2]  # [S, B, E]
+    att = torch.softmax(torch.einsum("sbe,tbe->bst", q, k) / E ** 0.5, -1)
+    ref = torch.einsum("bst,tbe->sbe", att, v).reshape(tokens * nb, E)
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    d = qkv.detach().cuda()
+    out = torch.empty(tokens * nb, E, device="cuda")
+    lse = torch.empty(nb, 1, tokens, device="cuda")
+    st, so = (3 * E, nb * 3 * E, 0), (E, nb * E, 0)
+    ops.attention(d, d[:, E:], d[:, 2 * E:], out, nb, 1, tokens, tokens, E, st, st, st, so, 1.0 / E ** 0.5, lse=lse)
+    assert (out.cpu() - ref.detach()).abs().max().item() < 2e-5
+    dqkv = torch.empty_like(d)
+    ops.attention_bwd(d, d[:, E:], d[:, 2 * E:], out, go.cuda(), lse, dqkv, dqkv[:, E:], dqkv[:, 2 * E:], nb, 1, tokens,
+                      tokens, E, st, st, st, so, so, st, st, st, 1.0 / E ** 0.5)
+    assert (dqkv.cpu() - qkv.grad).abs().max().item() < 5e-5

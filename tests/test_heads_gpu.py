@@ -68,3 +68,41 @@ def test_jmt_rejects_other_modalities():
     with pytest.raises(ValueError):
         JMT(task="CLASSIFICATION", modalities=["video", "bert"], tcn_settings=synth.TCN_SETTINGS, backbone_settings={},
             output_dim=7, root_dir="", device="cuda", model_name="JMT", load_backbone=False)
+
+
+@pytest.mark.parametrize("mt", [False, True])
+def test_jmt_fusion_many_tokens_vs_oracle(mt):
+    """The final stage attends over all L*B tokens: 8 clips x 40 frames = 320 tokens per stack slot,
+    several 128-query blocks and ragged key tiles in the flash kernels, forward and backward."""
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.fusion_heads import JMTFusion, MTFusion
+    from oracle.jmt import jmt_fusion
+    name = "MT" if mt else "JMT"
+    spec, alias = synth.jmt_spec(MODS, name)
+    sd = synth.make_state_dict(spec, alias, seed=71)
+    fsd = {k[len("fuse."):]: v for k, v in sd.items() if k.startswith("fuse.")}
+    fuse = (MTFusion() if mt else JMTFusion())
+    fuse.load_state_dict(fsd, strict=True)
+    fuse = fuse.cuda()
+    bsz, length = 8, 40
+    g = torch.Generator().manual_seed(72)
+    v = torch.randn(bsz, 128, length, generator=g, requires_grad=True)
+    a = torch.randn(bsz, 64, length, generator=g, requires_grad=True)
+    ref = jmt_fusion({"video": v, "vggish": a}, sd, "fuse.", mt=mt)  # [B, L, 128]
+    go = torch.randn(ref.shape, generator=g)
+    ref.backward(go)
+    vr = v.detach().transpose(1, 2).reshape(bsz * length, 128).contiguous().cuda().requires_grad_(True)
+    ar = a.detach().transpose(1, 2).reshape(bsz * length, 64).contiguous().cuda().requires_grad_(True)
+    out = fuse.forward_rows(vr, ar, bsz, length)
+    err_out = (out.detach().cpu().view(bsz, length, 128) - ref.detach()).abs().max().item()
+    assert err_out < 1e-5, err_out
+    out.backward(go.reshape(bsz * length, 128).cuda())
+    # Gradients: relative L2 error.  A max-norm bound is not meaningful here: with ~10^5 ReLU
+    # pre-activations per layer, one that lands within 1e-7 of zero flips its derivative between
+    # two correct fp32 evaluations (observed: exactly one element at this size, 4e-4 on dv).
+    dv = vr.grad.cpu().view(bsz, length, 128).transpose(1, 2)
+    da = ar.grad.cpu().view(bsz, length, 64).transpose(1, 2)
+    rel_v = ((dv - v.grad).norm() / v.grad.norm()).item()
+    rel_a = ((da - a.grad).norm() / a.grad.norm()).item()
+    assert rel_v < 2e-3 and rel_a < 2e-3, (rel_v, rel_a)
+    assert (dv - v.grad).abs().max().item() < 5e-3 and (da - a.grad).abs().max().item() < 5e-3

@@ -298,3 +298,30 @@ def test_trainer_windowed_inference_on_hip_model_vs_oracle():
         cnt[wd] += 1
     assert np.abs(per_video["clip0"]["logits"] - acc / cnt[:, None]).max() < 1e-4
     assert per_video["clip0"]["labels"].tolist() == [3] * n
+
+
+def test_lfan_reference_window_length_300_vs_oracle():
+    """The reference's default training window (300 frames, base/dataset.py windows 300/200): TCN receptive
+    field 121 frames, causal padding and dilation 8 inside a long sequence; feature modalities only."""
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.lfan import cross_entropy_loss
+    from oracle.lfan import cross_entropy_mean, lfan_forward
+    mods = ["bert", "vggish"]
+    sd = synth.lfan_state_dict(mods, n_cls=8, seed=17)
+    x, labels = synth.make_clip_batch(mods, 2, 300, seed=18, n_cls=8)
+    w = sd["regressor.weight"].clone().requires_grad_(True)
+    osd = dict(sd)
+    osd["regressor.weight"] = w
+    ref = lfan_forward(x, osd, mods, train=True)
+    rloss = cross_entropy_mean(ref, labels)
+    rloss.backward()
+    model = _build_lfan(mods, sd, 300, n_cls=8).train()
+    for net in model.temporal.values():
+        net.dropout = 0.0
+    model.fusion.layers.dropout.p = 0.0
+    out = model({k: v.cuda() for k, v in x.items()})
+    loss = cross_entropy_loss(out, labels.cuda())
+    loss.backward()
+    _close(out, ref, 2e-4)
+    assert abs(loss.item() - rloss.item()) < 1e-4
+    _close(model.regressor.weight.grad, w.grad, 1e-4)
