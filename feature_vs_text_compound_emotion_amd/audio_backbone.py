@@ -61,13 +61,17 @@ class VGGish(nn.Module):
                                         nn.Linear(4096, 128))
         self._packed, self._key = None, None
         self._mel = None
+        # "bf16x3": convs 2-6 and the three FCs on the split-bf16 kernels (fp32-class accuracy); "fp32": exact fp32
+        self.precision = "bf16x3"
 
     def _pack(self):
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
         if self._packed is None or key != self._key:
             if self.features[0].weight.device.type != "cuda":
                 raise RuntimeError("VGGish runs on the HIP kernels only: move the module to a GPU (no CPU fallback)")
-            self._packed = [ops.pack_conv_weight(self.features[i].weight.detach().contiguous()) for i in CONV_IDX]
+            convs = [ops.pack_conv_weight(self.features[i].weight.detach().contiguous()) for i in CONV_IDX]
+            self._packed = {"convs": convs, "convs_b3": [None] + [ops.split_bf16(w) for w in convs[1:]],
+                            "fc_b3": [ops.split_bf16(self.embeddings[i].weight.detach().contiguous()) for i in (0, 2, 4)]}
             self._key = key
         return self._packed
 
@@ -88,6 +92,9 @@ class VGGish(nn.Module):
         x = torch.as_tensor(x).to(dev).float().contiguous()
         packed = self._pack()
         n = x.shape[0]
+        if self.precision == "bf16x3":
+            return self._forward_b3(x, packed, n)
+        packed = packed["convs"]
         y = x.view(n, 1, x.shape[1], x.shape[2])  # NCHW with C = 1
         for j, i in enumerate(CONV_IDX):
             y = ops.conv2d(y, packed[j], 3, 3, pad=(1, 1), bias=self.features[i].bias.detach(), act1=ops.ACT_RELU,
@@ -100,6 +107,26 @@ class VGGish(nn.Module):
         e = ops.linear(e, fc[0].weight.detach(), bias=fc[0].bias.detach(), act=ops.ACT_RELU, split_k=split)
         e = ops.linear(e, fc[2].weight.detach(), bias=fc[2].bias.detach(), act=ops.ACT_RELU, split_k=split)
         return ops.linear(e, fc[4].weight.detach(), bias=fc[4].bias.detach(), split_k=split)
+
+    def _forward_b3(self, x, packed, n):
+        """Layer 1 (Cin = 1) on the fp32 small-Cin kernel, everything else on the bf16x3 kernels.  Max-pooling
+        needs the fp32 value, so a conv that feeds a pool writes fp32 and the pooled map is re-split."""
+        feats, fc = self.features, self.embeddings
+        y = ops.conv2d(x.view(n, 1, x.shape[1], x.shape[2]), packed["convs"][0], 3, 3, pad=(1, 1),
+                       bias=feats[0].bias.detach(), act1=ops.ACT_RELU, x_nchw=True)
+        cur = ops.split_bf16(ops.maxpool2x2_nhwc(y))
+        for j, i in list(enumerate(CONV_IDX))[1:]:
+            pooled = i in POOL_AFTER
+            r = ops.conv2d_b3(cur, packed["convs_b3"][j], 3, 3, pad=(1, 1), bias=feats[i].bias.detach(), act1=ops.ACT_RELU,
+                              out_f32=pooled, out_split=not pooled)
+            cur = ops.split_bf16(ops.maxpool2x2_nhwc(r["y"])) if pooled else r["split"]
+        k = cur.hi.numel() // n
+        e = cur.view(n, 1, 1, k)  # (H, W, C) flatten == the reference's transposes + view
+        split = max(1, min(8, 512 // max(1, (n + 127) // 128 * 32)))
+        e = ops.conv2d_b3(e, packed["fc_b3"][0], 1, 1, bias=fc[0].bias.detach(), act1=ops.ACT_RELU, split_k=split)["split"]
+        e = ops.conv2d_b3(e, packed["fc_b3"][1], 1, 1, bias=fc[2].bias.detach(), act1=ops.ACT_RELU, split_k=split)["split"]
+        return ops.conv2d_b3(e, packed["fc_b3"][2], 1, 1, bias=fc[4].bias.detach(), split_k=split, out_f32=True,
+                             out_split=False)["y"].view(n, -1)
 
     # ---------------------------------------------------------------- front end
     def wav_int16_to_examples(self, pcm_int16, sample_rate, window_sec=0.96, hop_sec=0.96):

@@ -535,7 +535,8 @@ static int launch_b3(const ConvArgs &a, hipStream_t st) {
 
 // tile ids (desc.tile): 0 auto; 1 = 128x128 BK32, 2 = 128x64 BK32, 3 = 128x128 BK64, 4 = 64x128 BK32, 5 = 64x64 BK32,
 // 6 = ping-pong 128x128 (measured 5-10 % slower than 1: kept as a tested A/B variant), 9 = timing-only ablation.
-// Measured and dropped: 256x128 / 128x256 tiles with 128x64 per wave (2 waves/SIMD, -3..-8 %).  The no-staging
+// Measured and dropped: 256x128 / 128x256 tiles with 128x64 per wave (2 waves/SIMD, -3..-8 %), 256x64 for the
+// Cout = 64 layers (-13 % vs 128x64).  The no-staging
 // ablation reaches ~500 TFLOP/s effective and LDS store bandwidth (32 KB per K step at ~80 B/clk against 768
 // MFMA cycles) is what the register-staged structure runs into; LDS-DMA staging is the next step.
 int conv_b3_tile_dims(int tile, int Cout, long long M, int &bm, int &bn, int &bk) {

@@ -39,7 +39,8 @@ def test_logmel_batched_and_ragged_lengths():
         net.wav_int16_to_examples(pcm, 44100)
 
 
-def test_vggish_matches_reference_fixture_and_oracle():
+@pytest.mark.parametrize("precision", ["bf16x3", "fp32"])
+def test_vggish_matches_reference_fixture_and_oracle(precision):
     import oracle
     from feature_vs_text_compound_emotion_amd import synth
     from feature_vs_text_compound_emotion_amd.audio_backbone import AudioBackbone
@@ -49,6 +50,7 @@ def test_vggish_matches_reference_fixture_and_oracle():
     ab = AudioBackbone()
     assert set(ab.backbone.state_dict()) == set(vsd)
     ab.backbone.load_state_dict(vsd, strict=True)
+    ab.backbone.precision = precision
     ab = ab.cuda().eval()
     x = golden("logmel_examples.npz")["examples"][:n]
     with torch.no_grad():
