@@ -10,8 +10,7 @@ namespace cer {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int BK = 32;
-constexpr int PITCH = 36;  // floats per LDS row
+constexpr int BK = 32;  // K padding granule of packed weights ([Cout][Kpad], Kpad % 32 == 0)
 
 struct ConvArgs {
     const float *x, *w, *in_scale, *in_shift, *bias, *alpha, *res, *mask;
