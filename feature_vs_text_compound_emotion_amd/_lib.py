@@ -79,6 +79,9 @@ _SIGNATURES = {
     "cer_add_inplace": (c_int, [_P, _P, c_size_t, _P]),
     "cer_l2norm_rows": (c_int, [_P, _P, c_int, c_int, _P]),
     "cer_maxpool2x2_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cer_frames_band_rows": (c_int, []),
+    "cer_frames_transform": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int,
+                                     c_int, c_float, c_float, _P, _P, _P]),
 }
 
 _lib = None

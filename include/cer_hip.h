@@ -135,6 +135,22 @@ int cer_l2norm_rows(const float *x, float *y, int rows, int cols, void *stream);
 /* max-pool 2x2 stride 2 on NHWC (reference models/backbone.py:45-46). */
 int cer_maxpool2x2_nhwc(const float *x, float *y, int N, int H, int W, int C, void *stream);
 
+/* Video-frame input transform of the reference Dataset, fused (base/dataset.py:487-508,
+ * base/transforms3D.py:33-143): uint8 frames [n][H][W][3] -> GroupScale(size) (== PIL
+ * Image.resize BILINEAR, Pillow's 8-bit fixed-point antialiased triangle filter, reproduced
+ * bit for bit) -> crop (x1, y1) to crop x crop -> optional horizontal flip -> /255 -> (v - mean) / std,
+ * written as fp32 [n][3][crop][crop] (and optionally the uint8 HWC image before the float stage).
+ * hbounds/vbounds [size][2] = (first input index, tap count); hcoef/vcoef [size][ksize] = Pillow's
+ * integer coefficients (2^22 scale), computed by the host.  crop_xyf [groups][3] = (x1, y1, flip), one
+ * triple per `frames_per_group` consecutive frames (GroupRandomCrop / GroupRandomHorizontalFlip draw
+ * once per clip).  max_band_rows = the largest number of input rows any band of cer_frames_band_rows()
+ * output rows needs (sizes the LDS). */
+int cer_frames_band_rows(void);
+int cer_frames_transform(const uint8_t *frames, int n_frames, int H, int W, const int32_t *hbounds, const int32_t *hcoef,
+                         int hksize, const int32_t *vbounds, const int32_t *vcoef, int vksize, int size, int crop,
+                         const int32_t *crop_xyf, int frames_per_group, int max_band_rows, float mean, float stdv,
+                         float *out, uint8_t *out_u8, void *stream);
+
 /* ------------------------------------------------------------------------
  * Trainable tail (rows = B*L frames, channels-last).  Forward AND backward,
  * because this is the part of the model the reference actually trains

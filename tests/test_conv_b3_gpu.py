@@ -25,7 +25,11 @@ def test_split_is_round_to_nearest_and_exact_to_16_bits():
 @pytest.mark.parametrize("n,cin,cout,hw,k,stride,tile", [
     (3, 64, 64, 12, 3, 1, 0), (2, 128, 256, 10, 3, 1, 1), (2, 128, 256, 10, 3, 2, 3), (4, 64, 128, 9, 1, 2, 0),
     (2, 256, 256, 10, 3, 1, 4), (3, 64, 96, 7, 3, 1, 5), (2, 128, 256, 10, 3, 1, 2), (2, 128, 256, 10, 3, 1, 6),
-    (5, 64, 128, 9, 3, 2, 6), (3, 96, 100, 7, 3, 1, 6)])
+    (5, 64, 128, 9, 3, 2, 6), (3, 96, 100, 7, 3, 1, 6),
+    # LDS-DMA staged tiles (zero padding through out-of-range buffer offsets, source-side swizzle)
+    (2, 128, 256, 10, 3, 1, 11), (5, 64, 128, 9, 3, 2, 11), (3, 96, 100, 7, 3, 1, 11), (4, 64, 128, 9, 1, 2, 11),
+    (3, 64, 64, 12, 3, 1, 12), (3, 64, 96, 7, 3, 1, 12), (2, 256, 256, 10, 3, 1, 14), (2, 128, 256, 10, 3, 2, 14),
+    (3, 64, 96, 7, 3, 1, 15), (1, 32, 40, 5, 3, 1, 15), (7, 512, 512, 5, 3, 1, 11)])
 def test_conv_b3_matches_fp32(n, cin, cout, hw, k, stride, tile):
     from feature_vs_text_compound_emotion_amd import ops
     x, w = _setup(n, cin, cout, hw, k, n * 100 + cin + cout)
@@ -39,7 +43,40 @@ def test_conv_b3_matches_fp32(n, cin, cout, hw, k, stride, tile):
     assert (r["split"].float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 6e-5
 
 
-@pytest.mark.parametrize("tile", [0, 6])
+@pytest.mark.parametrize("n,cin,cout,hw,k,dil,tile", [
+    # window kernel (input window resident in LDS, taps = row shifts, out-of-image taps read a zero slot):
+    # tiles that span several small images, M % 256 != 0, ragged Cout, 1 and 8 channel chunks, 5x5, dilation
+    (3, 64, 128, 12, 3, 1, 31), (40, 32, 128, 5, 3, 1, 31), (2, 256, 256, 10, 3, 1, 31), (3, 96, 100, 7, 3, 1, 31),
+    (1, 64, 128, 28, 3, 1, 31), (2, 64, 64, 12, 3, 1, 32), (3, 64, 96, 7, 3, 1, 32), (1, 128, 64, 30, 3, 1, 32),
+    (3, 64, 128, 12, 3, 1, 33), (9, 128, 256, 5, 3, 1, 33), (2, 64, 128, 9, 5, 1, 31), (2, 64, 64, 11, 3, 2, 32),
+    (1, 64, 128, 56, 3, 1, 31)])
+def test_conv_b3_window_kernel(n, cin, cout, hw, k, dil, tile):
+    from feature_vs_text_compound_emotion_amd import ops
+    x, w = _setup(n, cin, cout, hw, k, n * 100 + cin + cout)
+    pad = dil * (k // 2)
+    ref = F.conv2d(x, w, None, 1, pad, dil)
+    xs = ops.split_bf16(x.permute(0, 2, 3, 1).contiguous().cuda())
+    ws = ops.split_bf16(ops.pack_conv_weight(w.cuda()))
+    r = ops.conv2d_b3(xs, ws, k, k, stride=1, dil=(dil, dil), pad=(pad, pad), tile=tile, out_f32=True, out_split=True,
+                      want_stats=True)
+    got = r["y"].cpu().permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() < 3e-5
+    assert (r["split"].float().cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 6e-5
+    st = r["stats"].cpu().sum(0)
+    assert (st[0] - ref.sum((0, 2, 3))).abs().max().item() < 1e-2
+    assert (st[1] - (ref * ref).sum((0, 2, 3))).abs().max().item() < 1e-2
+
+
+def test_conv_b3_window_kernel_rejects_what_it_cannot_take():
+    from feature_vs_text_compound_emotion_amd import ops
+    x, w = _setup(2, 64, 64, 10, 3, 1)
+    xs = ops.split_bf16(x.permute(0, 2, 3, 1).contiguous().cuda())
+    ws = ops.split_bf16(ops.pack_conv_weight(w.cuda()))
+    with pytest.raises(RuntimeError, match="window"):
+        ops.conv2d_b3(xs, ws, 3, 3, stride=2, pad=(1, 1), tile=31)
+
+
+@pytest.mark.parametrize("tile", [0, 6, 11, 12])
 def test_conv_b3_fused_epilogue_outputs(tile):
     from feature_vs_text_compound_emotion_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -72,6 +109,6 @@ def test_linear_b3_split_k():
     ref = F.linear(x, w, b)
     xs = ops.split_bf16(x.cuda().view(m, 1, 1, k))
     ws = ops.split_bf16(w.cuda().contiguous())
-    for tile in (0, 6):
+    for tile in (0, 6, 11, 15):
         r = ops.conv2d_b3(xs, ws, 1, 1, bias=b.cuda(), split_k=5, out_f32=True, out_split=False, tile=tile)
         assert (r["y"].view(m, cout).cpu() - ref).abs().max().item() < 5e-5
