@@ -737,6 +737,224 @@ __global__ __launch_bounds__(256, 2) void conv_b3_dma_kernel(ConvArgs p) {
     }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ int swz16(int q) { return (0x78 >> (2 * q)) & 3; }  // F = {0, 2, 3, 1}
+
+// The same kernel on v_mfma_f32_16x16x32_bf16: one MFMA eats the whole 32-deep K step of a 16x16 tile.  Same
+// FLOPs per cycle as 32x32x16, but the chip holds a higher clock on this shape under the power limit that
+// governs bf16 MFMA loops on real data (MI355X_MICROARCH.md, DVFS note 7) -- measured here, not assumed: see
+// DESIGN.md section 4.  Fragment = row (lane & 15), 16-byte k-chunk (lane >> 4); a ds_read_b128 lane group then
+// covers 16 different rows, 8 with chunk c and 8 with chunk c^1, and the XOR swizzle that keeps that conflict
+// free is slot = chunk ^ F[(row >> 2) & 3] with F = {0, 2, 3, 1} (applied on the DMA's source side as before).
+template <int BM, int BN, int WP, int WC>
+__global__ __launch_bounds__(256, 2) void conv_b3_dma16_kernel(ConvArgs p) {
+    static_assert(WP * WC == 4 && BM % 64 == 0 && BN % 64 == 0, "4 waves; 1-KiB pieces are dealt round-robin to them");
+    constexpr int BKT = 32, ROWB = BKT * 2;        // bytes per row and plane
+    constexpr int XP = BM / 64, WQ = BN / 64;      // 1-KiB pieces per wave and plane
+    constexpr int PX = BM * ROWB, PW = BN * ROWB;  // plane sizes in bytes
+    constexpr int BUF = 2 * PX + 2 * PW;
+    constexpr int TP = BM / (16 * WP), TC = BN / (16 * WC);  // 16x16 tiles per wave
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem_b3[];
+    unsigned char *smem = reinterpret_cast<unsigned char *>(smem_b3);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave % WP, wc = wave / WP;
+    const int kg = lane >> 4, l15 = lane & 15;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, c0 = tile_n * BN;
+    const int split = blockIdx.z;
+    const int s_begin = split * p.steps_per_split;
+    const int s_end = min(p.steps, s_begin + p.steps_per_split);
+
+    // ---- DMA assignment: wave w moves pieces w, w+4, ... of every plane; in a piece lane l owns
+    // row l/4, LDS slot l%4 ----
+    const int prow = lane >> 2, slot = lane & 3;
+    unsigned x_off[XP], x_taps[XP], w_off[WQ];
+    long long tile_base;  // bytes from the plane base to the tile's first row, tap (0,0)
+    {
+        const int hw = p.Ho * p.Wo;
+        const int mm = m0 < p.M ? m0 : 0;
+        const int n = mm / hw, r = mm - n * hw;
+        const int ho = r / p.Wo, wo = r - ho * p.Wo;
+        tile_base = ((long long)(n * p.H + ho * p.stride - p.pad_t) * p.W + (wo * p.stride - p.pad_l)) * p.x_ld * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+        const int row = (wave + 4 * i) * 16 + prow;
+        const int chunk = slot ^ swz16((row >> 2) & 3);
+        const int m = m0 + row;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int hw = p.Ho * p.Wo;
+        const int n = mm / hw, r = mm - n * hw;
+        const int ho = r / p.Wo, wo = r - ho * p.Wo;
+        const int hi0 = ho * p.stride - p.pad_t, wi0 = wo * p.stride - p.pad_l;
+        const long long rb = ((long long)(n * p.H + hi0) * p.W + wi0) * p.x_ld * 2;
+        x_off[i] = (unsigned)(rb - tile_base) + chunk * 16u;
+        unsigned bits = 0;
+        if (ok) {
+            for (int t = 0; t < p.KH * p.KW; ++t) {
+                const int kh = t / p.KW, kw = t - kh * p.KW;
+                const int hi = hi0 + kh * p.dil_h, wi = wi0 + kw * p.dil_w;
+                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) bits |= 1u << t;
+            }
+        }
+        x_taps[i] = bits;
+    }
+#pragma unroll
+    for (int i = 0; i < WQ; ++i) {
+        const int row = (wave + 4 * i) * 16 + prow;
+        const int chunk = slot ^ swz16((row >> 2) & 3);
+        w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + chunk * 8) * 2) : OOB;
+    }
+
+    auto issue = [&](int s, int buf) {
+        const int tap = s / p.cin_steps, cc = s - tap * p.cin_steps;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const long long soff = tile_base + ((long long)(kh * p.dil_h * p.W + kw * p.dil_w) * p.x_ld + cc * BKT) * 2;
+        const size_t woff = ((size_t)c0 * p.Kpad + (size_t)s * BKT) * 2;
+        char *xhb = const_cast<char *>(reinterpret_cast<const char *>(p.x_hi)) + soff;
+        char *xlb = const_cast<char *>(reinterpret_cast<const char *>(p.x_lo)) + soff;
+        char *whb = const_cast<char *>(reinterpret_cast<const char *>(p.w_hi)) + woff;
+        char *wlb = const_cast<char *>(reinterpret_cast<const char *>(p.w_lo)) + woff;
+        constexpr int XREC = (int)OOB, WREC = (int)OOB;
+        const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc(xhb, 0, XREC, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc(xlb, 0, XREC, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rwh = __builtin_amdgcn_make_buffer_rsrc(whb, 0, WREC, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rwl = __builtin_amdgcn_make_buffer_rsrc(wlb, 0, WREC, 0x00020000);
+        const unsigned tapbit = 1u << tap;
+        unsigned char *dst = smem + buf * BUF + wave * 1024;
+#pragma unroll
+        for (int i = 0; i < XP; ++i) {
+            const int vo = (int)((x_taps[i] & tapbit) ? x_off[i] : OOB);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_ptr_t)(dst + i * 4096), 16, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_ptr_t)(dst + PX + i * 4096), 16, vo, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < WQ; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwh, (lds_ptr_t)(dst + 2 * PX + i * 4096), 16, (int)w_off[i], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, (lds_ptr_t)(dst + 2 * PX + PW + i * 4096), 16, (int)w_off[i], 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[TC][TP];
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+
+    if (s_begin < s_end) issue(s_begin, 0);
+
+    // fragment addresses: row * 64 bytes + swizzled slot of k-chunk kg
+    const int sw = swz16((l15 >> 2) & 3);
+    const int arow = (wc * TC * 16 + l15) * ROWB + ((kg ^ sw) << 4);  // A = weights: row = cout
+    const int brow = (wp * TP * 16 + l15) * ROWB + ((kg ^ sw) << 4);  // B = activations: row = pixel
+    for (int s = s_begin; s < s_end; ++s) {
+        const int cur = (s - s_begin) & 1;
+        // every wave has seen its own pieces of step s land, and (barrier) everyone else's; the barrier also
+        // closes the reads of step s-1, whose buffer the next DMA overwrites
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < s_end) issue(s + 1, cur ^ 1);
+        const unsigned char *Xh = smem + cur * BUF, *Xl = Xh + PX, *Wh = Xh + 2 * PX, *Wl = Wh + PW;
+        bf16x8 ah[TC], al[TC], bh[TP], bl[TP];
+#pragma unroll
+        for (int a = 0; a < TC; ++a) {
+            ah[a] = as_bf16x8(*reinterpret_cast<const u32x4 *>(Wh + arow + a * 16 * ROWB));
+            al[a] = as_bf16x8(*reinterpret_cast<const u32x4 *>(Wl + arow + a * 16 * ROWB));
+        }
+#pragma unroll
+        for (int b = 0; b < TP; ++b) {
+            bh[b] = as_bf16x8(*reinterpret_cast<const u32x4 *>(Xh + brow + b * 16 * ROWB));
+            bl[b] = as_bf16x8(*reinterpret_cast<const u32x4 *>(Xl + brow + b * 16 * ROWB));
+        }
+#pragma unroll
+        for (int a = 0; a < TC; ++a)
+#pragma unroll
+            for (int b = 0; b < TP; ++b) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            }
+    }
+
+    // ---- epilogue: D[i = cout][j = pixel] of a 16x16 tile: lane holds couts 4*(lane>>4) + 0..3 of pixel lane&15 ----
+    static_for<TP>([&](auto B) {
+        constexpr int b = decltype(B)::v;
+        const int m = m0 + (wp * TP + b) * 16 + l15;
+        static_for<TC>([&](auto A) {
+            constexpr int a = decltype(A)::v;
+            const int c = c0 + (wc * TC + a) * 16 + 4 * kg;
+            float v[4] = {acc[a][b][0], acc[a][b][1], acc[a][b][2], acc[a][b][3]};
+            if (m < p.M && c < p.Cout) {
+                if (p.split_k > 1) {
+                    float *dst = p.y + ((size_t)split * p.M + m) * p.Cout + c;
+                    if (((p.Cout & 3) == 0) && c + 3 < p.Cout) {
+                        *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c + e < p.Cout) dst[e] = v[e];
+                    }
+                } else {
+                    epilogue_store4(p, m, c, v);
+                }
+            }
+        });
+    });
+
+    if (p.stats) {
+        __syncthreads();  // the last step's fragment reads are done: the planes can be reused
+        float *red = reinterpret_cast<float *>(smem_b3);  // [WP][2][BN]
+        static_for<TC>([&](auto A) {
+            constexpr int a = decltype(A)::v;
+            static_for<4>([&](auto Rg) {
+                constexpr int r = decltype(Rg)::v;
+                float s1 = 0.f, s2 = 0.f;
+                static_for<TP>([&](auto B) {
+                    constexpr int b = decltype(B)::v;
+                    const int m = m0 + (wp * TP + b) * 16 + l15;
+                    const float v = (m < p.M) ? acc[a][b][r] : 0.f;
+                    s1 += v;
+                    s2 += v * v;
+                });
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    s1 += __shfl_xor(s1, o);
+                    s2 += __shfl_xor(s2, o);
+                }
+                if (l15 == 0) {
+                    const int ci = (wc * TC + a) * 16 + 4 * kg + r;
+                    red[(wp * 2 + 0) * BN + ci] = s1;
+                    red[(wp * 2 + 1) * BN + ci] = s2;
+                }
+            });
+        });
+        __syncthreads();
+        if (tid < BN && c0 + tid < p.Cout) {
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < WP; ++w) {
+                s1 += red[(w * 2 + 0) * BN + tid];
+                s2 += red[(w * 2 + 1) * BN + tid];
+            }
+            p.stats[((size_t)tile_m * 2 + 0) * p.Cout + c0 + tid] = s1;
+            p.stats[((size_t)tile_m * 2 + 1) * p.Cout + c0 + tid] = s2;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // Window variant for "same" convolutions (stride 1, Ho == H, Wo == W): what limits the kernels above
 // is the L2 -> LDS traffic of BOTH operands (zero-record ablations: activations dropped +56 %, weights
@@ -864,67 +1082,77 @@ __global__ __launch_bounds__(512) void conv_b3_win_kernel(ConvArgs p, int NP) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
-    // ---- prologue: the whole window of chunk 0, weight slices 0 and 1 ----
+    // ---- software pipeline ----
+    // Step s = (chunk cc, tap).  At the top of step s every wave waits for its own DMAs (weight slice s+1 and the
+    // window pieces issued during step s-1) and meets the others at the barrier; it then issues slice s+2 and one
+    // window piece of chunk cc+1, runs the 24 MFMAs of step s on fragments that are ALREADY in registers, and -- between
+    // them -- reads the fragments of step s+1 (slice s+1 and the resident window are visible since the barrier).
+    // So nothing but the barrier itself separates the MFMA streams of consecutive steps.
+    struct Frags {
+        bf16x8 ah[TC], al[TC], bh[TP], bl[TP];
+    };
+    auto load_frags = [&](Frags &f, int cc, int tap, int ring, int kk) {
+        const unsigned char *Wh = Wr + ring * WSLOT, *Wl = Wh + PW;
+        const int kh = tap / p.KW, kw = tap - kh * p.KW;
+        const int toff = kh * p.dil_h * p.W + kw * p.dil_w;
+        const int xbo = (cc & 1) * XBUF, zo = 4 * XPL + 3 * WSLOT + 1024;  // LDS byte offsets (ints: a select
+                                                                             // between pointers decays to flat loads)
+#pragma unroll
+        for (int a = 0; a < TC; ++a) {
+            f.ah[a] = as_bf16x8(*reinterpret_cast<const u32x4 *>(Wh + ((arow + a * 32 * ROWB) ^ (kk << 5))));
+            f.al[a] = as_bf16x8(*reinterpret_cast<const u32x4 *>(Wl + ((arow + a * 32 * ROWB) ^ (kk << 5))));
+        }
+#pragma unroll
+        for (int b = 0; b < TP; ++b) {
+            const int r = rbase[b] + toff;
+            const int a0 = (r << 6) | ((((r >> 2) ^ half) & 3) << 4);
+            const bool ok = (x_taps[b] >> tap) & 1u;
+            f.bh[b] = as_bf16x8(*reinterpret_cast<const u32x4 *>(smem + ((ok ? xbo + a0 : zo) ^ (kk << 5))));
+            f.bl[b] = as_bf16x8(*reinterpret_cast<const u32x4 *>(smem + ((ok ? xbo + XPL + a0 : zo) ^ (kk << 5))));
+        }
+    };
+    auto mma = [&](const Frags &f) {
+#pragma unroll
+        for (int a = 0; a < TC; ++a)
+#pragma unroll
+            for (int b = 0; b < TP; ++b) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[a], f.bh[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[a], f.bl[b], acc[a][b], 0, 0, 0);
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[a], f.bh[b], acc[a][b], 0, 0, 0);
+            }
+    };
+
+    // prologue: the whole window of chunk 0, weight slices 0 and 1
     for (int t = 0; t < 8; ++t) issue_x(0, t);
     issue_w(0, 0, 0);
     if (total > 1) issue_w(T > 1 ? 0 : 1, T > 1 ? 1 : 0, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    Frags f0, f1;  // k-substeps 0 and 1 of the CURRENT step
+    load_frags(f0, 0, 0, 0, 0);
+    load_frags(f1, 0, 0, 0, 1);
 
-    int s = 0, ring = 0;
-    for (int cc = 0; cc < p.cin_steps; ++cc) {
-        for (int tap = 0; tap < T; ++tap, ++s) {
-            // slice s (issued two steps ago) and every window piece older than one step have landed
-            if (s > 0 && s + 1 < total) {
-                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NISSUE) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            issue_x(cc + 1, tap);
-            if (s + 2 < total) {
-                int t2 = tap + 2, c2 = cc;
-                if (t2 >= T) { t2 -= T; c2 += 1; }
-                if (t2 >= T) { t2 -= T; c2 += 1; }  // T == 1
-                const int r2 = ring >= 1 ? ring - 1 : 2;  // (ring + 2) % 3
-                issue_w(c2, t2, r2);
-            }
-            const unsigned char *Wh = Wr + ring * WSLOT, *Wl = Wh + PW;
-            ring = ring == 2 ? 0 : ring + 1;
-            const int kh = tap / p.KW, kw = tap - kh * p.KW;
-            const int toff = kh * p.dil_h * p.W + kw * p.dil_w;
-            // LDS byte offsets (ints, so that the reads stay ds_read_b128: a select between pointers decays to flat)
-            const int xbo = (cc & 1) * XBUF, zo = 4 * XPL + 3 * WSLOT + 1024;
-            int xoh[TP], xol[TP];
-#pragma unroll
-            for (int b = 0; b < TP; ++b) {
-                const int r = rbase[b] + toff;
-                const int a0 = (r << 6) | ((((r >> 2) ^ half) & 3) << 4);
-                const bool ok = (x_taps[b] >> tap) & 1u;
-                xoh[b] = ok ? xbo + a0 : zo;
-                xol[b] = ok ? xbo + XPL + a0 : zo;
-            }
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) {
-                bf16x8 ah[TC], al[TC], bh[TP], bl[TP];
-#pragma unroll
-                for (int a = 0; a < TC; ++a) {
-                    ah[a] = as_bf16x8(*reinterpret_cast<const u32x4 *>(Wh + ((arow + a * 32 * ROWB) ^ (kk << 5))));
-                    al[a] = as_bf16x8(*reinterpret_cast<const u32x4 *>(Wl + ((arow + a * 32 * ROWB) ^ (kk << 5))));
-                }
-#pragma unroll
-                for (int b = 0; b < TP; ++b) {
-                    bh[b] = as_bf16x8(*reinterpret_cast<const u32x4 *>(smem + (xoh[b] ^ (kk << 5))));
-                    bl[b] = as_bf16x8(*reinterpret_cast<const u32x4 *>(smem + (xol[b] ^ (kk << 5))));
-                }
-#pragma unroll
-                for (int a = 0; a < TC; ++a)
-#pragma unroll
-                    for (int b = 0; b < TP; ++b) {
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-                    }
-            }
+    int ring = 0, cc = 0, tap = 0;
+    for (int s = 0; s < total; ++s) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue_x(cc + 1, tap);
+        int t1 = tap + 1, c1 = cc;
+        if (t1 >= T) { t1 = 0; c1 += 1; }
+        int t2 = t1 + 1, c2 = c1;
+        if (t2 >= T) { t2 = 0; c2 += 1; }
+        const int r1 = ring == 2 ? 0 : ring + 1, r2 = r1 == 2 ? 0 : r1 + 1;
+        if (s + 2 < total) issue_w(c2, t2, r2);
+        const bool more = s + 1 < total;
+        Frags n0;
+        mma(f0);
+        if (more) load_frags(n0, c1, t1, r1, 0);
+        mma(f1);
+        if (more) {
+            load_frags(f1, c1, t1, r1, 1);
+            f0 = n0;
         }
+        ring = r1; cc = c1; tap = t1;
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sink pieces of the last steps
 
@@ -1026,6 +1254,18 @@ static int launch_b3_dma(const ConvArgs &a, hipStream_t st) {
     return CER_OK;
 }
 
+template <int BM, int BN, int WP, int WC>
+static int launch_b3_dma16(const ConvArgs &a, hipStream_t st) {
+    if ((long long)BN * a.Kpad * 2 >= (1ll << 31))
+        return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3, LDS-DMA): weight panel exceeds 31-bit offsets");
+    const size_t lds = (size_t)2 * (2 * BM + 2 * BN) * 64;
+    auto k = conv_b3_dma16_kernel<BM, BN, WP, WC>;
+    if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, a.split_k), dim3(256), lds, st, a);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
 // pieces (1 KiB = 16 window rows) per activation plane, or 0 when the window kernel cannot take the conv
 static int win_pieces(const ConvArgs &a, int bm, int bn) {
     if (a.stride != 1 || a.Ho != a.H || a.Wo != a.W || a.split_k != 1) return 0;
@@ -1057,8 +1297,17 @@ static int launch_b3_win(const ConvArgs &a, hipStream_t st) {
 // Cout = 64 layers (-13 % vs 128x64).  The no-staging
 // ablation reaches ~500 TFLOP/s effective and LDS store bandwidth (32 KB per K step at ~80 B/clk against 768
 // MFMA cycles) is what the register-staged structure runs into; LDS-DMA staging is the next step.
-int conv_b3_tile_dims(int tile, int Cout, long long M, int &bm, int &bn, int &bk) {
-    if (tile == 0) tile = Cout <= 64 ? 2 : ((M + 127) / 128 * ((Cout + 127) / 128) >= 512 ? 1 : (Cout >= 128 ? 4 : 5));
+int conv_b3_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, int &bk) {
+    if (tile == 0) {
+        // measured per layer shape on MI355X (tools/bench_conv.py): the LDS-DMA kernels beat their
+        // register-staged twins everywhere and the 16x16x32 MFMA shape beats 32x32x16 by 8-18 % (higher sustained clock);
+        // 128x64 tiles win while K is short (Cin <= 128: more, shorter blocks hide the prologue / epilogue), 128x128
+        // once K >= 2304; small grids take 64-row tiles
+        const long long t128 = (M + 127) / 128 * ((Cout + 127) / 128);
+        if (Cout <= 64) tile = 42;
+        else if (t128 >= 512) tile = K <= 1152 ? 42 : 41;
+        else tile = Cout >= 128 ? 44 : 45;
+    }
     switch (tile) {
         case 1: bm = 128; bn = 128; bk = 32; break;
         case 2: bm = 128; bn = 64; bk = 32; break;
@@ -1072,6 +1321,10 @@ int conv_b3_tile_dims(int tile, int Cout, long long M, int &bm, int &bn, int &bk
         case 14: bm = 64; bn = 128; bk = 32; break;
         case 15: bm = 64; bn = 64; bk = 32; break;
         case 21: case 22: case 23: bm = 128; bn = 128; bk = 32; break;  // timing-only ablations of tile 11
+        case 41: bm = 128; bn = 128; bk = 32; break;  // 41/42/44/45: tiles 11/12/14/15 on v_mfma_f32_16x16x32_bf16
+        case 42: bm = 128; bn = 64; bk = 32; break;
+        case 44: bm = 64; bn = 128; bk = 32; break;
+        case 45: bm = 64; bn = 64; bk = 32; break;
         case 31: bm = 256; bn = 128; bk = 32; break;
         case 32: bm = 256; bn = 64; bk = 32; break;
         case 33: bm = 128; bn = 128; bk = 32; break;
@@ -1100,6 +1353,10 @@ int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 12: return launch_b3_dma<128, 64, 2, 2>(a, st);
         case 14: return launch_b3_dma<64, 128, 1, 4>(a, st);
         case 15: return launch_b3_dma<64, 64, 2, 2>(a, st);
+        case 41: return launch_b3_dma16<128, 128, 2, 2>(a, st);
+        case 42: return launch_b3_dma16<128, 64, 2, 2>(a, st);
+        case 44: return launch_b3_dma16<64, 128, 1, 4>(a, st);
+        case 45: return launch_b3_dma16<64, 64, 2, 2>(a, st);
         case 31: return launch_b3_win<256, 128, 4, 2>(a, st);
         case 32: return launch_b3_win<256, 64, 8, 1>(a, st);
         case 33: return launch_b3_win<128, 128, 2, 4>(a, st);

@@ -446,7 +446,7 @@ static int validate_desc(const cer_conv_desc *d) {
 }
 
 namespace cer {
-int conv_b3_tile_dims(int tile, int Cout, long long M, int &bm, int &bn, int &bk);
+int conv_b3_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, int &bk);
 }
 
 extern "C" int cer_conv2d_stats_tiles(const cer_conv_desc *d, int bf16x3) {
@@ -454,7 +454,7 @@ extern "C" int cer_conv2d_stats_tiles(const cer_conv_desc *d, int bf16x3) {
     const int M = d->N * d->Ho * d->Wo;
     int bm, bn, bk;
     if (bf16x3) {
-        const int t = conv_b3_tile_dims(d->tile, d->Cout, M, bm, bn, bk);
+        const int t = conv_b3_tile_dims(d->tile, d->Cout, M, cer_conv_kpad(d->KH, d->KW, d->Cin), bm, bn, bk);
         if (!t) return 0;
         if (t == 6) return 2 * ((M + bm - 1) / bm);  // the ping-pong kernel writes one row per pixel half-tile
     } else {
@@ -469,7 +469,7 @@ extern "C" size_t cer_conv2d_workspace_bytes(const cer_conv_desc *d) {
 }
 
 namespace cer {
-int conv_b3_tile_dims(int tile, int Cout, long long M, int &bm, int &bn, int &bk);
+int conv_b3_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, int &bk);
 int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st);
 }  // namespace cer
 
@@ -524,7 +524,7 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
     const bool vec = (d->Cin % 32) == 0;
     int tile, bm, bn, bk, esz;
     if (b3) {
-        tile = conv_b3_tile_dims(d->tile, d->Cout, a.M, bm, bn, bk);
+        tile = conv_b3_tile_dims(d->tile, d->Cout, a.M, a.Kpad, bm, bn, bk);
         if (!tile) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3): unknown tile id");
         if (d->Cin % bk != 0 || (a.x_ld & 7))
             return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3): Cin must be a multiple of the K step and x_ld of 8");

@@ -45,8 +45,14 @@ def main():
             xs, ws = ops.split_bf16(x), ops.split_bf16(w)
             for tile in [int(t) for t in a.tiles.split(",")]:
                 run = lambda: ops.conv2d_b3(xs, ws, k, k, stride=stride, pad=(k // 2, k // 2), tile=tile)  # noqa: E731
-                for _ in range(2):
-                    run()
+                try:
+                    for _ in range(2):
+                        run()
+                except RuntimeError as err:
+                    if "UNSUPPORTED" in str(err) or "status -2" in str(err):
+                        print(f"{name:18s} H={h:3d} b3 tile={tile}  unsupported", flush=True)
+                        continue
+                    raise
                 torch.cuda.synchronize()
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
