@@ -29,7 +29,7 @@ class ConvIO(Structure):
     """cer_conv_io: every pointer of one conv launch (see include/cer_hip.h)."""
     _fields_ = [(n, c_void_p) for n in (
         "x", "w", "x_hi", "x_lo", "w_hi", "w_lo", "in_scale", "in_shift", "bias", "alpha", "residual", "mask",
-        "res_hi", "res_lo", "y", "aux", "stats", "y_hi", "y_lo", "s2", "t2", "y2_hi", "y2_lo")]
+        "res_hi", "res_lo", "y", "aux", "stats", "y_hi", "y_lo", "s2", "t2", "y2_hi", "y2_lo", "bias9")]
 
 
 _SIGNATURES = {
@@ -48,6 +48,7 @@ _SIGNATURES = {
     "cer_bn_apply_stats_tiles": (c_int, [c_int]),
     "cer_bn_apply_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, _P]),
+    "cer_bn_apply_nhwc_b3": (c_int, [_P] * 14 + [c_int] * 7 + [_P]),
     "cer_pack_conv_weight": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cer_weight_norm_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "cer_weight_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),

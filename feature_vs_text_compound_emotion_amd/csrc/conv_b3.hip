@@ -746,11 +746,13 @@ __device__ __forceinline__ int swz16(int q) { return (0x78 >> (2 * q)) & 3; }  /
 // DESIGN.md section 4.  Fragment = row (lane & 15), 16-byte k-chunk (lane >> 4); a ds_read_b128 lane group then
 // covers 16 different rows, 8 with chunk c and 8 with chunk c^1, and the XOR swizzle that keeps that conflict
 // free is slot = chunk ^ F[(row >> 2) & 3] with F = {0, 2, 3, 1} (applied on the DMA's source side as before).
-template <int BM, int BN, int WP, int WC>
-__global__ __launch_bounds__(256, 2) void conv_b3_dma16_kernel(ConvArgs p) {
-    static_assert(WP * WC == 4 && BM % 64 == 0 && BN % 64 == 0, "4 waves; 1-KiB pieces are dealt round-robin to them");
+// NW = 4 waves (two blocks per CU) or 8 waves: the 256x256 tile of 8 waves x (128 pixels x 64 couts) halves the
+// L2 -> LDS bytes per FLOP of the 128x128 tile and the LDS fragment reads per MFMA drop by a quarter; one block per CU.
+template <int BM, int BN, int WP, int WC, int NW = 4>
+__global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_b3_dma16_kernel(ConvArgs p) {
+    static_assert(WP * WC == NW && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "1-KiB pieces are dealt round-robin to the waves");
     constexpr int BKT = 32, ROWB = BKT * 2;        // bytes per row and plane
-    constexpr int XP = BM / 64, WQ = BN / 64;      // 1-KiB pieces per wave and plane
+    constexpr int XP = BM / (16 * NW), WQ = BN / (16 * NW);  // 1-KiB pieces per wave and plane
     constexpr int PX = BM * ROWB, PW = BN * ROWB;  // plane sizes in bytes
     constexpr int BUF = 2 * PX + 2 * PW;
     constexpr int TP = BM / (16 * WP), TC = BN / (16 * WC);  // 16x16 tiles per wave
@@ -789,7 +791,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_dma16_kernel(ConvArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
-        const int row = (wave + 4 * i) * 16 + prow;
+        const int row = (wave + NW * i) * 16 + prow;
         const int chunk = slot ^ swz16((row >> 2) & 3);
         const int m = m0 + row;
         const bool ok = m < p.M;
@@ -812,7 +814,7 @@ __global__ __launch_bounds__(256, 2) void conv_b3_dma16_kernel(ConvArgs p) {
     }
 #pragma unroll
     for (int i = 0; i < WQ; ++i) {
-        const int row = (wave + 4 * i) * 16 + prow;
+        const int row = (wave + NW * i) * 16 + prow;
         const int chunk = slot ^ swz16((row >> 2) & 3);
         w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + chunk * 8) * 2) : OOB;
     }
@@ -836,13 +838,13 @@ __global__ __launch_bounds__(256, 2) void conv_b3_dma16_kernel(ConvArgs p) {
 #pragma unroll
         for (int i = 0; i < XP; ++i) {
             const int vo = (int)((x_taps[i] & tapbit) ? x_off[i] : OOB);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_ptr_t)(dst + i * 4096), 16, vo, 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_ptr_t)(dst + PX + i * 4096), 16, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_ptr_t)(dst + i * (NW * 1024)), 16, vo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_ptr_t)(dst + PX + i * (NW * 1024)), 16, vo, 0, 0, 0);
         }
 #pragma unroll
         for (int i = 0; i < WQ; ++i) {
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwh, (lds_ptr_t)(dst + 2 * PX + i * 4096), 16, (int)w_off[i], 0, 0, 0);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, (lds_ptr_t)(dst + 2 * PX + PW + i * 4096), 16, (int)w_off[i], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwh, (lds_ptr_t)(dst + 2 * PX + i * (NW * 1024)), 16, (int)w_off[i], 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rwl, (lds_ptr_t)(dst + 2 * PX + PW + i * (NW * 1024)), 16, (int)w_off[i], 0, 0, 0);
         }
     };
 
@@ -1254,14 +1256,14 @@ static int launch_b3_dma(const ConvArgs &a, hipStream_t st) {
     return CER_OK;
 }
 
-template <int BM, int BN, int WP, int WC>
+template <int BM, int BN, int WP, int WC, int NW = 4>
 static int launch_b3_dma16(const ConvArgs &a, hipStream_t st) {
     if ((long long)BN * a.Kpad * 2 >= (1ll << 31))
         return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3, LDS-DMA): weight panel exceeds 31-bit offsets");
     const size_t lds = (size_t)2 * (2 * BM + 2 * BN) * 64;
-    auto k = conv_b3_dma16_kernel<BM, BN, WP, WC>;
+    auto k = conv_b3_dma16_kernel<BM, BN, WP, WC, NW>;
     if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, a.split_k), dim3(256), lds, st, a);
+    CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, a.split_k), dim3(NW * 64), lds, st, a);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }
@@ -1325,6 +1327,8 @@ int conv_b3_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, 
         case 42: bm = 128; bn = 64; bk = 32; break;
         case 44: bm = 64; bn = 128; bk = 32; break;
         case 45: bm = 64; bn = 64; bk = 32; break;
+        case 46: bm = 256; bn = 256; bk = 32; break;  // 8 waves
+        case 47: bm = 256; bn = 128; bk = 32; break;  // 8 waves
         case 31: bm = 256; bn = 128; bk = 32; break;
         case 32: bm = 256; bn = 64; bk = 32; break;
         case 33: bm = 128; bn = 128; bk = 32; break;
@@ -1357,6 +1361,8 @@ int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 42: return launch_b3_dma16<128, 64, 2, 2>(a, st);
         case 44: return launch_b3_dma16<64, 128, 1, 4>(a, st);
         case 45: return launch_b3_dma16<64, 64, 2, 2>(a, st);
+        case 46: return launch_b3_dma16<256, 256, 2, 4, 8>(a, st);
+        case 47: return launch_b3_dma16<256, 128, 4, 2, 8>(a, st);
         case 31: return launch_b3_win<256, 128, 4, 2>(a, st);
         case 32: return launch_b3_win<256, 64, 8, 1>(a, st);
         case 33: return launch_b3_win<128, 128, 2, 4>(a, st);

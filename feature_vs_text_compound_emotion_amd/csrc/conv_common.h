@@ -22,6 +22,7 @@ struct ConvArgs {
     const uint16_t *x_hi, *x_lo, *w_hi, *w_lo;  // b3 kernel inputs (x/w above are unused then)
     const uint16_t *res_hi, *res_lo;            // residual given as a split tensor (alternative to res)
     uint16_t *y_hi, *y_lo;                      // optional split copy of the output
+    const float *bias9;                         // optional [9][Cout] border-dependent bias (replaces bias)
     const float *s2, *t2;                       // optional second output: out * s2[c] + t2[c] ...
     uint16_t *y2_hi, *y2_lo;                    // ... stored split (the NEXT layer's pre-conv BatchNorm)
     int x_ld, y_ld;  // row pitches (elements) of x pixels / y rows
@@ -85,8 +86,16 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c,
     }
     const size_t yoff = (size_t)m * p.y_ld + c;
     const size_t doff = (size_t)m * p.Cout + c;  // dense offset (mask, aux)
+    const float *bias = p.bias;
+    if (p.bias9) {
+        const int hw = p.Ho * p.Wo;
+        const int r = m % hw;
+        const int ho = r / p.Wo, wo = r - ho * p.Wo;
+        const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
+        bias = p.bias9 + (size_t)(3 * ry + rx) * p.Cout;
+    }
     if (vec && ((p.y_ld & 3) == 0) && c + 3 < p.Cout) {
-        float4 b = p.bias ? *reinterpret_cast<const float4 *>(p.bias + c) : make_float4(0, 0, 0, 0);
+        float4 b = bias ? *reinterpret_cast<const float4 *>(bias + c) : make_float4(0, 0, 0, 0);
         float4 a = (p.act1 == CER_ACT_PRELU) ? *reinterpret_cast<const float4 *>(p.alpha + c) : make_float4(0, 0, 0, 0);
         float bb[4] = {b.x, b.y, b.z, b.w}, aa[4] = {a.x, a.y, a.z, a.w};
         float rr[4] = {0, 0, 0, 0}, mm[4] = {1, 1, 1, 1};
@@ -122,7 +131,7 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c,
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             if (c + e < p.Cout) {
-                float t = v[e] + (p.bias ? p.bias[c + e] : 0.f);
+                float t = v[e] + (bias ? bias[c + e] : 0.f);
                 t = act_apply(t, p.act1, p.act1 == CER_ACT_PRELU ? p.alpha[c + e] : 0.f, p.slope);
                 if (p.mask) t *= p.mask[doff + e];
                 if (p.aux) p.aux[doff + e] = t;

@@ -509,6 +509,9 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
     a.x_hi = io->x_hi; a.x_lo = io->x_lo; a.w_hi = io->w_hi; a.w_lo = io->w_lo;
     a.res_hi = io->res_hi; a.res_lo = io->res_lo; a.y_hi = io->y_hi; a.y_lo = io->y_lo;
     a.s2 = io->s2; a.t2 = io->t2; a.y2_hi = io->y2_hi; a.y2_lo = io->y2_lo;
+    a.bias9 = io->bias9;
+    if (io->bias9 && (io->bias || d->stride != 1 || d->Ho != d->H || d->Wo != d->W || d->H < 2 || d->W < 2 || d->split_k > 1))
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: bias9 replaces bias and needs a stride-1 same conv on >= 2x2 images without split-K");
     a.x_ld = d->x_ld > 0 ? d->x_ld : d->Cin;
     a.y_ld = d->y_ld > 0 ? d->y_ld : d->Cout;
     if (a.x_ld < d->Cin || a.y_ld < d->Cout || ((d->Cin % 32) == 0 && (a.x_ld & 3) != 0))

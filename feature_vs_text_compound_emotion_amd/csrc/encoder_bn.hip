@@ -8,7 +8,7 @@
 // double precision into a per-channel scale/shift and performs torch's running-stat update;
 // bn_apply_nhwc is the one bandwidth-bound pass per unit that normalises the conv result, adds
 // the (optionally normalised) shortcut and gathers the statistics of the sum for the next unit.
-#include "cer_internal.h"
+#include "conv_common.h"
 
 namespace cer {
 
@@ -68,6 +68,8 @@ struct ApplyArgs {
     const float *y, *scale, *shift, *alpha, *res, *res_scale, *res_shift, *mask;
     float *out, *stats;
     int P, Ho, Wo, C, res_stride, Hr, Wr, rows_per_block;
+    const uint16_t *res_hi, *res_lo;  // residual as a split tensor (alternative to res)
+    uint16_t *out_hi, *out_lo;        // result stored split (besides / instead of out)
 };
 
 // Threads are laid out [rows_per_pass][C/4]; each thread keeps its 4 channels for the whole block
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256) void bn_apply_nhwc_kernel(ApplyArgs p) {
                 const float4 m = *reinterpret_cast<const float4 *>(p.mask + off);
                 o[0] *= m.x; o[1] *= m.y; o[2] *= m.z; o[3] *= m.w;
             }
-            if (p.res) {
+            if (p.res || p.res_hi) {
                 size_t roff;
                 if (p.res_stride == 1 && p.Hr == p.Ho && p.Wr == p.Wo) {
                     roff = off;
@@ -112,11 +114,20 @@ __global__ __launch_bounds__(256) void bn_apply_nhwc_kernel(ApplyArgs p) {
                     const int ho = q / p.Wo, wo = q - ho * p.Wo;
                     roff = ((size_t)(n * p.Hr + ho * p.res_stride) * p.Wr + wo * p.res_stride) * p.C + c;
                 }
-                const float4 x = *reinterpret_cast<const float4 *>(p.res + roff);
+                float4 x;
+                if (p.res) {
+                    x = *reinterpret_cast<const float4 *>(p.res + roff);
+                } else {
+                    const ushort4 h = *reinterpret_cast<const ushort4 *>(p.res_hi + roff);
+                    const ushort4 l = *reinterpret_cast<const ushort4 *>(p.res_lo + roff);
+                    x = make_float4(bf16_to_f32(h.x) + bf16_to_f32(l.x), bf16_to_f32(h.y) + bf16_to_f32(l.y),
+                                    bf16_to_f32(h.z) + bf16_to_f32(l.z), bf16_to_f32(h.w) + bf16_to_f32(l.w));
+                }
                 o[0] += x.x * rs.x + rt.x; o[1] += x.y * rs.y + rt.y;
                 o[2] += x.z * rs.z + rt.z; o[3] += x.w * rs.w + rt.w;
             }
-            *reinterpret_cast<float4 *>(p.out + off) = make_float4(o[0], o[1], o[2], o[3]);
+            if (p.out) *reinterpret_cast<float4 *>(p.out + off) = make_float4(o[0], o[1], o[2], o[3]);
+            if (p.out_hi) store_split4(p.out_hi + off, p.out_lo + off, o);
 #pragma unroll
             for (int e = 0; e < 4; ++e) { s1[e] += o[e]; s2[e] += o[e] * o[e]; }
         }
@@ -178,21 +189,42 @@ extern "C" int cer_bn_apply_stats_tiles(int P) {
     return (P + r - 1) / r;
 }
 
+static int bn_apply_launch(const float *y, const float *scale, const float *shift, const float *alpha, const float *res,
+                           const uint16_t *res_hi, const uint16_t *res_lo, const float *res_scale, const float *res_shift,
+                           const float *mask, float *out, uint16_t *out_hi, uint16_t *out_lo, float *stats, int N, int Ho,
+                           int Wo, int C, int res_stride, int Hr, int Wr, void *stream) {
+    if (!y || !scale || !shift || (!out && !out_hi) || N <= 0 || Ho <= 0 || Wo <= 0 || C < 4 || C > 1024 || (C & 3) ||
+        (256 % (C / 4)) != 0)
+        return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc: C must be 16..1024 with C/4 dividing 256");
+    if ((long long)N * Ho * Wo >= (1ll << 31)) return cer_set_error(CER_ERR_UNSUPPORTED, "bn_apply_nhwc: too many pixels");
+    if ((res_hi == nullptr) != (res_lo == nullptr) || (out_hi == nullptr) != (out_lo == nullptr) || (res && res_hi))
+        return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc: split tensors need both planes; residual is fp32 OR split");
+    const bool has_res = res || res_hi;
+    if ((res_scale == nullptr) != (res_shift == nullptr) || (res_scale && !has_res))
+        return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc: residual affine needs res, res_scale and res_shift");
+    if (has_res && (res_stride <= 0 || (Ho - 1) * res_stride >= Hr || (Wo - 1) * res_stride >= Wr))
+        return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc: residual geometry out of range");
+    ApplyArgs a{y, scale, shift, alpha, res, res_scale, res_shift, mask, out, stats,
+                N * Ho * Wo, Ho, Wo, C, res_stride, Hr, Wr, apply_rows_per_block(N * Ho * Wo),
+                res_hi, res_lo, out_hi, out_lo};
+    CER_LAUNCH(bn_apply_nhwc_kernel, dim3(cer_bn_apply_stats_tiles(a.P)), dim3(256), 0, (hipStream_t)stream, a);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
 extern "C" int cer_bn_apply_nhwc(const float *y, const float *scale, const float *shift, const float *alpha,
                                  const float *res, const float *res_scale, const float *res_shift, const float *mask,
                                  float *out, float *stats, int N, int Ho, int Wo, int C, int res_stride, int Hr, int Wr,
                                  void *stream) {
-    if (!y || !scale || !shift || !out || N <= 0 || Ho <= 0 || Wo <= 0 || C < 4 || C > 1024 || (C & 3) ||
-        (256 % (C / 4)) != 0)
-        return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc: C must be 16..1024 with C/4 dividing 256");
-    if ((long long)N * Ho * Wo >= (1ll << 31)) return cer_set_error(CER_ERR_UNSUPPORTED, "bn_apply_nhwc: too many pixels");
-    if ((res_scale == nullptr) != (res_shift == nullptr) || (res_scale && !res))
-        return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc: residual affine needs res, res_scale and res_shift");
-    if (res && (res_stride <= 0 || (Ho - 1) * res_stride >= Hr || (Wo - 1) * res_stride >= Wr))
-        return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc: residual geometry out of range");
-    ApplyArgs a{y, scale, shift, alpha, res, res_scale, res_shift, mask, out, stats,
-                N * Ho * Wo, Ho, Wo, C, res_stride, Hr, Wr, apply_rows_per_block(N * Ho * Wo)};
-    CER_LAUNCH(bn_apply_nhwc_kernel, dim3(cer_bn_apply_stats_tiles(a.P)), dim3(256), 0, (hipStream_t)stream, a);
-    CER_HIP_CHECK(hipGetLastError());
-    return CER_OK;
+    if (!out) return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc: out is NULL");
+    return bn_apply_launch(y, scale, shift, alpha, res, nullptr, nullptr, res_scale, res_shift, mask, out, nullptr, nullptr,
+                           stats, N, Ho, Wo, C, res_stride, Hr, Wr, stream);
+}
+
+extern "C" int cer_bn_apply_nhwc_b3(const float *y, const float *scale, const float *shift, const float *alpha,
+                                    const float *res, const uint16_t *res_hi, const uint16_t *res_lo, const float *res_scale,
+                                    const float *res_shift, const float *mask, float *out, uint16_t *out_hi, uint16_t *out_lo,
+                                    float *stats, int N, int Ho, int Wo, int C, int res_stride, int Hr, int Wr, void *stream) {
+    return bn_apply_launch(y, scale, shift, alpha, res, res_hi, res_lo, res_scale, res_shift, mask, out, out_hi, out_lo, stats,
+                           N, Ho, Wo, C, res_stride, Hr, Wr, stream);
 }

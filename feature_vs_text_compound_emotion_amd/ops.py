@@ -172,7 +172,7 @@ def _dev_bf16(t, name):
 
 def conv2d_b3(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bias=None, alpha=None, residual=None,
               res_stride=1, act1=ACT_NONE, act2=ACT_NONE, slope=LEAKY_SLOPE, split_k=1, tile=0, out_f32=False,
-              out_split=True, next_affine=None, want_stats=False):
+              out_split=True, next_affine=None, want_stats=False, bias9=None):
     """bf16x3 convolution.  x, w: Split tensors (x NHWC [N,H,W,Cin], w [Cout,Kpad]); residual: Split
     or fp32 tensor.  Returns a dict with the requested outputs: 'y' (fp32), 'split' (Split), 'next'
     (Split of out*s2+t2 when ``next_affine=(s2, t2)``), 'stats'."""
@@ -199,6 +199,11 @@ def conv2d_b3(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bi
     io.x_hi, io.x_lo, io.w_hi, io.w_lo = x.hi.data_ptr(), x.lo.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr()
     io.bias = bias.data_ptr() if bias is not None else None
     io.alpha = alpha.data_ptr() if alpha is not None else None
+    if bias9 is not None:
+        _dev_f32(bias9, "bias9")
+        if tuple(bias9.shape) != (9, cout):
+            raise ValueError("bias9 must be [9, Cout]")
+        io.bias9 = bias9.data_ptr()
     if residual is not None:
         rshape = residual.shape
         if rshape[0] != n or rshape[3] != cout:
@@ -298,6 +303,56 @@ def bn_apply_nhwc(y, scale, shift, alpha=None, res=None, res_stride=1, res_scale
                                 ptr(mask), ptr(out), ptr(stats), n, ho, wo, c, res_stride, hr, wr, current_stream()),
           "cer_bn_apply_nhwc")
     return (out, stats) if want_stats else out
+
+
+def bn_apply_nhwc_b3(y, scale, shift, alpha=None, res=None, res_stride=1, res_scale=None, res_shift=None, mask=None,
+                     want_stats=False, out_f32=False, out_split=True):
+    """``bn_apply_nhwc`` for the bf16x3 encoder: ``res`` may be a Split tensor, the result comes back as a Split
+    (what the next conv reads) and/or fp32.  Returns a dict with 'split', 'y', 'stats' as requested."""
+    for t, nme in ((y, "y"), (scale, "scale"), (shift, "shift"), (alpha, "alpha"), (res_scale, "res_scale"),
+                   (res_shift, "res_shift"), (mask, "mask")):
+        _dev_f32(t, nme)
+    n, ho, wo, c = y.shape
+    lib = _lib.load()
+    r_f32 = r_hi = r_lo = None
+    hr = wr = 0
+    if res is not None:
+        hr, wr = res.shape[1], res.shape[2]
+        if isinstance(res, Split):
+            _dev_bf16(res.hi, "res.hi")
+            r_hi, r_lo = res.hi, res.lo
+        else:
+            _dev_f32(res, "res")
+            r_f32 = res
+    out = {}
+    if out_f32:
+        out["y"] = torch.empty_like(y)
+    if out_split:
+        out["split"] = Split.empty(tuple(y.shape), y.device)
+    if want_stats:
+        out["stats"] = _empty((lib.cer_bn_apply_stats_tiles(n * ho * wo), 2, c), y)
+    sp = out.get("split")
+    check(lib.cer_bn_apply_nhwc_b3(ptr(y), ptr(scale), ptr(shift), ptr(alpha), ptr(r_f32), ptr(r_hi), ptr(r_lo),
+                                   ptr(res_scale), ptr(res_shift), ptr(mask), ptr(out.get("y")),
+                                   ptr(sp.hi) if sp is not None else None, ptr(sp.lo) if sp is not None else None,
+                                   ptr(out.get("stats")), n, ho, wo, c, res_stride, hr, wr, current_stream()),
+          "cer_bn_apply_nhwc_b3")
+    return out
+
+
+def fold_input_bn_3x3(w_oihw, scale, shift):
+    """Fold a per-input-channel affine (the batch-statistics BatchNorm in FRONT of a 3x3 / pad 1 / stride 1 conv) into
+    the conv: returns (packed weight of w * scale[cin], bias9 [9, Cout]).  conv(pad0(s*x + t)) = conv'(pad0(x)) +
+    sum over the taps INSIDE the image of W_tap . t, and that sum only depends on whether the output pixel sits on the
+    first / an inner / the last row and column (9 cases).  Weight-sized tensors only (torch ops as plumbing)."""
+    _dev_f32(w_oihw, "w")
+    if w_oihw.shape[2] != 3 or w_oihw.shape[3] != 3:
+        raise ValueError("fold_input_bn_3x3: 3x3 kernels only")
+    wp = pack_conv_weight((w_oihw * scale.view(1, -1, 1, 1)).contiguous())
+    bt = torch.einsum("oikl,i->okl", w_oihw, shift)                    # [Cout, 3, 3]: W_tap . t
+    rows = torch.stack([bt[:, 1:].sum(1), bt.sum(1), bt[:, :2].sum(1)])  # [ry, Cout, kw]: first / inner / last row
+    b9 = torch.stack([rows[:, :, 1:].sum(2), rows.sum(2), rows[:, :, :2].sum(2)], 1)  # [ry, rx, Cout]
+    return wp, b9.reshape(9, -1).contiguous()
 
 
 # ------------------------------------------------------------------ trainable tail

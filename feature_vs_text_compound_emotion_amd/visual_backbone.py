@@ -247,19 +247,26 @@ class IR50(nn.Module):
 
     def _forward_batch_stats_b3(self, x, head_mask=None):
         """Reference train() semantics (batch-statistics BatchNorm everywhere) with the convolutions on the
-        bf16x3 kernels.  Statistics and normalisation stay fp32; conv inputs are re-split after each
-        BatchNorm because its scale/shift only exist once the whole batch has been reduced."""
+        bf16x3 kernels.  Statistics and normalisation stay fp32.  Per unit there is ONE bandwidth-bound pass
+        (``bn_apply``: post-conv BatchNorm + shortcut + the statistics of the sum), which stores the unit output as
+        a split tensor; the NEXT unit's pre-conv BatchNorm -- whose scale/shift only exist once that pass has reduced
+        the whole batch -- is folded into its 3x3 conv (input scale into the weights, input shift into a
+        border-dependent bias, ``ops.fold_input_bn_3x3``), so no re-split pass over the activations is needed."""
         P = self.pack_train_b3()
         self._packed = self._packed_b3 = None  # running statistics are about to change
         n = x.shape[0]
         y0, st = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True)
         s, t = self._finalize(st, y0.numel() // 64, self.input_layer[1])
-        y, xst = ops.bn_apply_nhwc(y0, s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True)
-        del y0
-        for u, d in zip(self.body, P["units"]):
-            s1, t1 = self._finalize(xst, y.numel() // u.cin, u.res_layer[0])
-            tt = ops.conv2d_b3(ops.split_bf16(y, s1, t1), d["w1"], 3, 3, pad=(1, 1), alpha=u.res_layer[2].weight.detach(),
-                               act1=ops.ACT_PRELU)["split"]
+        r = ops.bn_apply_nhwc_b3(y0, s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True)
+        ys, xst = r["split"], r["stats"]
+        del y0, r
+        y = None
+        for i, (u, d) in enumerate(zip(self.body, P["units"])):
+            last = i + 1 == len(P["units"])
+            s1, t1 = self._finalize(xst, ys.hi.numel() // u.cin, u.res_layer[0])
+            w1, b9 = ops.fold_input_bn_3x3(u.res_layer[1].weight.detach(), s1, t1)
+            tt = ops.conv2d_b3(ys, ops.split_bf16(w1), 3, 3, pad=(1, 1), alpha=u.res_layer[2].weight.detach(),
+                               act1=ops.ACT_PRELU, bias9=b9)["split"]
             r = ops.conv2d_b3(tt, d["w2"], 3, 3, stride=u.stride, pad=(1, 1), out_f32=True, out_split=False,
                               want_stats=True)
             del tt
@@ -267,13 +274,15 @@ class IR50(nn.Module):
             cnt = z.numel() // u.depth
             s2, t2 = self._finalize(r["stats"], cnt, u.res_layer[4])
             if u.cin != u.depth:
-                rs = ops.conv2d_b3(ops.split_bf16(y), d["ws"], 1, 1, stride=u.stride, out_f32=True, out_split=False,
-                                   want_stats=True)
+                rs = ops.conv2d_b3(ys, d["ws"], 1, 1, stride=u.stride, out_f32=True, out_split=False, want_stats=True)
                 ss, stt = self._finalize(rs["stats"], cnt, u.shortcut_layer[1])
-                y, xst = ops.bn_apply_nhwc(z, s2, t2, res=rs["y"], res_scale=ss, res_shift=stt, want_stats=True)
+                o = ops.bn_apply_nhwc_b3(z, s2, t2, res=rs["y"], res_scale=ss, res_shift=stt, want_stats=True,
+                                         out_f32=last, out_split=not last)
             else:
-                y, xst = ops.bn_apply_nhwc(z, s2, t2, res=y, res_stride=u.stride, want_stats=True)
-            del z, r
+                o = ops.bn_apply_nhwc_b3(z, s2, t2, res=ys, res_stride=u.stride, want_stats=True, out_f32=last,
+                                         out_split=not last)
+            ys, xst, y = o.get("split"), o["stats"], o.get("y")
+            del z, r, o
         nn_, h, w, c = y.shape
         if h != self.head_hw or w != self.head_hw:
             raise RuntimeError(f"IR50 head was built for {self.head_hw}x{self.head_hw} feature maps but got {h}x{w}")
@@ -283,10 +292,10 @@ class IR50(nn.Module):
             self._dropout_calls += 1
             head_mask = ops.dropout_mask(tuple(y.shape), p_drop, 0x1f50 + self.dropout_seed, self._dropout_calls * y.numel(),
                                          y.device)
-        hfeat = ops.bn_apply_nhwc(y, s0, t0, mask=head_mask)
+        hfeat = ops.bn_apply_nhwc_b3(y, s0, t0, mask=head_mask)["split"]
         k = h * w * c
         fc, bn1 = self.output_layer[3], self.output_layer[4]
-        e = ops.conv2d_b3(ops.split_bf16(hfeat).view(n, 1, 1, k), P["head_w"], 1, 1, bias=fc.bias.detach(),
+        e = ops.conv2d_b3(hfeat.view(n, 1, 1, k), P["head_w"], 1, 1, bias=fc.bias.detach(),
                           split_k=self._head_split_k(n, k), out_f32=True, out_split=False)["y"].view(n, -1)
         e, _, _ = ops.bn_rows_fwd(e, bn1.weight.detach(), bn1.bias.detach(), bn1.running_mean, bn1.running_var, True,
                                   bn1.eps, bn1.momentum)

@@ -112,6 +112,10 @@ typedef struct cer_conv_io {
     uint16_t *y_hi, *y_lo;
     const float *s2, *t2;
     uint16_t *y2_hi, *y2_lo;
+    /* [9][Cout] border-dependent bias (replaces `bias`) of a stride-1 "same" conv whose INPUT BatchNorm was folded
+     * into the weights: row 3*ry + rx with ry / rx = 0 on the first, 2 on the last, 1 on the other output rows /
+     * columns -- the input shift only contributes through the taps that fall inside the image. */
+    const float *bias9;
 } cer_conv_io;
 
 int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, void *workspace, size_t workspace_bytes, void *stream);
@@ -229,6 +233,13 @@ int cer_bn_apply_nhwc(const float *y, const float *scale, const float *shift, co
                       const float *res, const float *res_scale, const float *res_shift, const float *mask,
                       float *out, float *stats, int N, int Ho, int Wo, int C, int res_stride, int Hr, int Wr,
                       void *stream);
+/* The same pass for the bf16x3 encoder: the residual may come as a split tensor (res_hi/res_lo instead of res) and
+ * the result is stored split (out_hi/out_lo) -- what the next conv reads directly -- and/or as fp32 (`out`); the
+ * statistics are taken from the fp32 value before the split. */
+int cer_bn_apply_nhwc_b3(const float *y, const float *scale, const float *shift, const float *alpha, const float *res,
+                         const uint16_t *res_hi, const uint16_t *res_lo, const float *res_scale, const float *res_shift,
+                         const float *mask, float *out, uint16_t *out_hi, uint16_t *out_lo, float *stats, int N, int Ho,
+                         int Wo, int C, int res_stride, int Hr, int Wr, void *stream);
 
 /* ------------------------------------------------------------------------
  * Audio / text encoder front ends and attention.

@@ -33,7 +33,10 @@ def test_split_is_round_to_nearest_and_exact_to_16_bits():
     # the same kernels on v_mfma_f32_16x16x32_bf16 (different fragment / accumulator layout and swizzle)
     (2, 128, 256, 10, 3, 1, 41), (5, 64, 128, 9, 3, 2, 41), (3, 96, 100, 7, 3, 1, 41), (4, 64, 128, 9, 1, 2, 41),
     (3, 64, 64, 12, 3, 1, 42), (3, 64, 96, 7, 3, 1, 42), (2, 256, 256, 10, 3, 1, 44), (2, 128, 256, 10, 3, 2, 44),
-    (3, 64, 96, 7, 3, 1, 45), (1, 32, 40, 5, 3, 1, 45), (7, 512, 512, 5, 3, 1, 41)])
+    (3, 64, 96, 7, 3, 1, 45), (1, 32, 40, 5, 3, 1, 45), (7, 512, 512, 5, 3, 1, 41),
+    # 8-wave 256x256 / 256x128 tiles
+    (4, 128, 256, 10, 3, 1, 46), (7, 256, 512, 5, 3, 2, 46), (3, 96, 300, 7, 3, 1, 46), (4, 64, 256, 9, 3, 2, 46),
+    (4, 128, 128, 10, 3, 1, 47), (3, 64, 100, 7, 3, 1, 47)])
 def test_conv_b3_matches_fp32(n, cin, cout, hw, k, stride, tile):
     from feature_vs_text_compound_emotion_amd import ops
     x, w = _setup(n, cin, cout, hw, k, n * 100 + cin + cout)
@@ -80,7 +83,7 @@ def test_conv_b3_window_kernel_rejects_what_it_cannot_take():
         ops.conv2d_b3(xs, ws, 3, 3, stride=2, pad=(1, 1), tile=31)
 
 
-@pytest.mark.parametrize("tile", [0, 6, 11, 12, 41, 42, 44])
+@pytest.mark.parametrize("tile", [0, 6, 11, 12, 41, 42, 44, 46, 47])
 def test_conv_b3_fused_epilogue_outputs(tile):
     from feature_vs_text_compound_emotion_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -113,6 +116,43 @@ def test_linear_b3_split_k():
     ref = F.linear(x, w, b)
     xs = ops.split_bf16(x.cuda().view(m, 1, 1, k))
     ws = ops.split_bf16(w.cuda().contiguous())
-    for tile in (0, 6, 11, 15, 41, 45):
+    for tile in (0, 6, 11, 15, 41, 45, 46):
         r = ops.conv2d_b3(xs, ws, 1, 1, bias=b.cuda(), split_k=5, out_f32=True, out_split=False, tile=tile)
         assert (r["y"].view(m, cout).cpu() - ref).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("n,cin,cout,hw,tile", [(2, 64, 64, 9, 0), (3, 64, 128, 6, 41), (2, 128, 256, 5, 11), (1, 64, 100, 12, 42)])
+def test_input_batchnorm_folded_into_the_conv(n, cin, cout, hw, tile):
+    """conv3x3(pad0(s*x + t)) == conv3x3'(pad0(x)) + bias9[border case]: the pre-conv BatchNorm of an IR unit folded
+    into the conv (ops.fold_input_bn_3x3) instead of a pass over the activations."""
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(hw * 7 + cout)
+    x, w = _setup(n, cin, cout, hw, 3, 11 * n + cout)
+    s1, t1 = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.5
+    alpha = torch.rand(cout, generator=g) * 0.3 + 0.1
+    z = F.conv2d(x * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1), w, None, 1, 1)
+    ref = torch.where(z >= 0, z, z * alpha.view(1, -1, 1, 1))
+    wp, b9 = ops.fold_input_bn_3x3(w.cuda(), s1.cuda(), t1.cuda())
+    xs = ops.split_bf16(x.permute(0, 2, 3, 1).contiguous().cuda())
+    r = ops.conv2d_b3(xs, ops.split_bf16(wp), 3, 3, pad=(1, 1), alpha=alpha.cuda(), act1=ops.ACT_PRELU, bias9=b9, tile=tile,
+                      out_f32=True, out_split=False)
+    assert (r["y"].cpu().permute(0, 3, 1, 2) - ref).abs().max().item() < 6e-5
+    with pytest.raises(RuntimeError, match="bias9"):
+        ops.conv2d_b3(xs, ops.split_bf16(wp), 3, 3, stride=2, pad=(1, 1), bias9=b9)
+
+
+def test_bn_apply_split_io():
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(9)
+    n, h, c = 3, 10, 64
+    z, res = torch.randn(n, 5, 5, c, generator=g), torch.randn(n, h, h, c, generator=g)
+    s, t = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    rs = ops.split_bf16(res.cuda())
+    o = ops.bn_apply_nhwc_b3(z.cuda(), s.cuda(), t.cuda(), res=rs, res_stride=2, want_stats=True, out_f32=True)
+    ref = z * s + t + rs.float().cpu()[:, ::2, ::2]
+    assert torch.equal(o["y"].cpu(), ops.bn_apply_nhwc(z.cuda(), s.cuda(), t.cuda(), res=rs.float(), res_stride=2).cpu())
+    assert (o["y"].cpu() - ref).abs().max().item() < 1e-5
+    assert torch.equal(o["split"].hi.cpu(), o["y"].cpu().bfloat16())
+    assert (o["split"].float().cpu() - o["y"].cpu()).abs().max().item() < 2e-4
+    st = o["stats"].cpu().sum(0)
+    assert (st[0] - ref.sum((0, 1, 2))).abs().max().item() < 1e-2
