@@ -26,6 +26,10 @@ import torch.distributed as dist  # noqa: E402
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak; the bf16x3 kernels spend 3 MFMAs per product -> 833.3 effective
 MODS = ["video", "vggish", "bert"]
+# kernel variant ids reported by cer_conv2d_b3_tile -> names as rocprofv3 prints them (csrc/conv_b3.hip)
+B3_KERNEL_NAMES = {41: "cer::conv_b3_dma16_kernel<128, 128, 2, 2, 4>", 42: "cer::conv_b3_dma16_kernel<128, 64, 2, 2, 4>",
+                   44: "cer::conv_b3_dma16_kernel<64, 128, 1, 4, 4>", 45: "cer::conv_b3_dma16_kernel<64, 64, 2, 2, 4>",
+                   46: "cer::conv_b3_dma16_kernel<256, 256, 2, 4, 8>"}
 
 
 def ir50_forward_flops(hw):
@@ -60,7 +64,7 @@ def measured_traffic(hw, batch, length, encoders, precision):
     (tools/collect_traffic.py: FETCH_SIZE x2 + WRITE_SIZE, separate passes, gfx950 corrections).  PMC
     counters cannot be read from inside the timed process, so the value is looked up by configuration
     and is null when no profile of this exact configuration has been committed."""
-    path = os.path.join(ROOT, "profiles", f"round1_traffic_{precision}_hw{hw}.json")
+    path = os.path.join(ROOT, "profiles", f"round1b_traffic_{precision}_hw{hw}.json")
     try:
         t = json.load(open(path))
     except (OSError, ValueError):
@@ -179,8 +183,8 @@ def main():
                          "off: pre-computed per-frame features, as the reference trainer feeds them")
     a = ap.parse_args()
 
-    from feature_vs_text_compound_emotion_amd import synth
-    from feature_vs_text_compound_emotion_amd.data_parallel import ClipDataParallel, init_process_group_from_env
+    from feature_vs_text_compound_emotion_amd import ops, synth
+    from feature_vs_text_compound_emotion_amd.data_parallel import ClipDataParallel, FlatNesterovSGD, init_process_group_from_env
     from feature_vs_text_compound_emotion_amd.lfan import cross_entropy_loss
 
     # CER_BENCH_BACKEND=gloo rehearses the N>1 path on a one-GPU box (all ranks share cuda:0); the driver's
@@ -199,7 +203,8 @@ def main():
     model.spatial["visual"].backbone.precision = a.precision
     model.train()
     ddp = ClipDataParallel(model, world_size=world)
-    opt = torch.optim.SGD(params=ddp.params, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=True)  # lr 1e-3 (F8)
+    # the reference's torch.optim.SGD(momentum .9, nesterov, wd 1e-4, lr 1e-3 -- F8) as one fused launch over flat buffers
+    opt = FlatNesterovSGD(ddp, lr=1e-3, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=True)
     x, labels = synth.make_clip_batch(MODS, a.batch, a.length, hw=a.hw, seed=1234 + rank)
     x = {k: v.to(dev) for k, v in x.items()}
     labels = labels.to(dev)
@@ -243,12 +248,14 @@ def main():
     for _ in range(a.warmup):
         step()
     ev.clear()
+    trace = ops.CONV_TRACE = [] if a.precision == "bf16x3" else None  # HIP events around every bf16x3 conv launch
     fence()
     t0 = time.perf_counter()
     for _ in range(a.steps):
         loss = step()
     fence()
     dt = time.perf_counter() - t0
+    ops.CONV_TRACE = None
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -259,6 +266,23 @@ def main():
     achieved = flops / (enc_ms * 1e-3) / 1e12
     b3 = a.precision == "bf16x3"
     peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if b3 else FP32_MFMA_PEAK_TFLOPS
+
+    # per kernel variant: algorithmic FLOPs of its launches / their HIP-event durations (launch stream), over the timed steps
+    kernels = {}
+    for tile, fl, e0, e1 in (trace or []):
+        k = kernels.setdefault(B3_KERNEL_NAMES.get(tile, f"conv_b3 tile {tile}"), {"launches": 0, "flops": 0.0, "ms": 0.0})
+        k["launches"] += 1
+        k["flops"] += fl
+        k["ms"] += e0.elapsed_time(e1)
+    for k in kernels.values():
+        k["launches_per_step"] = k["launches"] / a.steps
+        k["avg_launch_ms"] = k["ms"] / k["launches"]
+        k["flops_per_launch"] = k["flops"] / k["launches"]
+        k["achieved_tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12
+        k["frac"] = k["achieved_tflops"] / peak
+        k["ms_per_step"] = k.pop("ms") / a.steps
+        del k["flops"]
+    dominant = max(kernels, key=lambda n: kernels[n]["ms_per_step"]) if kernels else None
 
     alt = None
     if world == 1 and b3 and not a.no_alt:
@@ -280,6 +304,29 @@ def main():
                             "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach1 / FP32_MFMA_PEAK_TFLOPS,
                             "ms_per_step_in_kernel": ms1}}
         model.spatial["visual"].backbone.precision = a.precision
+    span = {"what": ("whole IR-50 forward (51 bf16x3 implicit-GEMM convs + head FC, fp32 stem, batch-statistics BatchNorm "
+                     "passes): algorithmic IR-50 FLOPs of the step / HIP-event span of the encoder forward" if b3 else
+                     "whole IR-50 forward on cer::conv_igemm_kernel (v_mfma_f32_32x32x2_f32)"),
+            "achieved": achieved, "frac": achieved / peak, "ms_per_step_in_kernel": enc_ms, "algorithmic_flops_per_step": flops}
+    traffic_note = ("HBM bytes per step over all conv kernel launches (rocprofv3 PMC passes, profiles/*traffic*_hw*.json: "
+                    "FETCH_SIZE x2 + WRITE_SIZE; the x2 read correction is calibrated for 128-B requests and may over-count "
+                    "64-B row segments); algorithmic minimum 18.6 MB/frame @40x40, 584 MB/frame @224x224 (SURVEY 8d)")
+    if dominant is not None:
+        kd = kernels[dominant]
+        roofline = {"bound": "mfma", "kernel": dominant, "achieved": kd["achieved_tflops"], "peak": peak, "unit": "TFLOP/s",
+                    "frac": kd["frac"], "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product (bf16x3)",
+                    "avg_launch_ms": kd["avg_launch_ms"], "launches_per_step": kd["launches_per_step"],
+                    "algorithmic_flops_per_launch": kd["flops_per_launch"],
+                    "definition": "algorithmic FLOPs (2*M*Cout*Cin*KH*KW) of this kernel's launches / their summed HIP-event "
+                                  "durations on the launch stream over the timed steps",
+                    "traffic": measured_traffic(a.hw, a.batch, a.length, a.encoders, a.precision), "traffic_note": traffic_note,
+                    "all_kernels": kernels, "encoder_span": span}
+    else:
+        roofline = {"bound": "mfma", "kernel": "cer::conv_igemm_kernel (IR-50 forward: 52 implicit-GEMM convs + head FC, "
+                                               "v_mfma_f32_32x32x2_f32)", "achieved": achieved, "peak": peak,
+                    "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": "fp32 MFMA peak",
+                    "traffic": measured_traffic(a.hw, a.batch, a.length, a.encoders, a.precision), "traffic_note": traffic_note,
+                    "algorithmic_flops_per_step": flops, "ms_per_step_in_kernel": enc_ms}
     if rank == 0:
         res = {
             "metric": "training clips/sec (32-frame tri-modal clip)",
@@ -291,7 +338,7 @@ def main():
             "dtype": "bf16x3 (split hi/lo bf16 operands, fp32 accumulate; fp32-class accuracy)" if b3 else "f32",
             "data": "synthetic",
             "config": {"workload": f"LFAN tri-modal training step: frozen IR-50 forward on {a.batch}x{a.length} frames "
-                                   f"of {a.hw}x{a.hw} + TCN/fusion/regressor forward+backward + CE + Nesterov SGD; "
+                                   f"of {a.hw}x{a.hw} + TCN/fusion/regressor forward+backward + CE + fused Nesterov SGD; "
                                    + ("VGGish (log-mel of 1 s PCM, 32 examples/clip) and BERT-base (64-token sentence) run on "
                                       "the GPU inside the step" if a.encoders == "on" else
                                       "vggish/bert as pre-computed per-frame features (as the reference trainer feeds them)"),
@@ -299,22 +346,7 @@ def main():
                        "clips_per_gpu": a.batch, "global_batch": a.batch * world, "frames_per_clip": a.length,
                        "frame_hw": a.hw, "n_classes": 7, "conv_precision": a.precision, "parallelism": f"dp{world} over clips, flat-bucket RCCL all-reduce",
                        "loss": float(loss.item())},
-            "roofline": {"bound": "mfma",
-                         "kernel": ("cer::conv_b3_kernel (IR-50 forward: 51 implicit-GEMM convs + head FC on "
-                                    "v_mfma_f32_32x32x16_bf16, 3 MFMAs per product; stem on the fp32 kernel; span includes the "
-                                    "batch-statistics BatchNorm passes)" if b3 else
-                                    "cer::conv_igemm_kernel (IR-50 forward: 52 implicit-GEMM convs + head FC, "
-                                    "v_mfma_f32_32x32x2_f32)"),
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "peak_note": ("dense bf16 MFMA peak 2500 TFLOP/s / 3 products per multiply" if b3 else
-                                       "fp32 MFMA peak"),
-                         "traffic": measured_traffic(a.hw, a.batch, a.length, a.encoders, a.precision),
-                         "traffic_note": "HBM bytes per step over all conv kernel launches (rocprofv3 PMC passes, "
-                                         "profiles/round1_traffic_<precision>_hw*.json: FETCH_SIZE x2 + WRITE_SIZE; the x2 "
-                                         "read correction is calibrated for 128-B requests and may over-count the bf16x3 "
-                                         "kernel's 64-B row segments); algorithmic minimum 18.6 MB/frame @40x40, "
-                                         "584 MB/frame @224x224 (SURVEY 8d)",
-                         "algorithmic_flops_per_step": flops, "ms_per_step_in_kernel": enc_ms},
+            "roofline": roofline,
         }
         if alt is not None:
             res["fp32_path"] = alt

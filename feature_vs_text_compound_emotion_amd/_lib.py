@@ -40,6 +40,7 @@ _SIGNATURES = {
     "cer_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "cer_conv2d_stats_tiles": (c_int, [POINTER(ConvDesc), c_int]),
     "cer_conv2d_run": (c_int, [POINTER(ConvDesc), POINTER(ConvIO), _P, c_size_t, _P]),
+    "cer_conv2d_b3_tile": (c_int, [POINTER(ConvDesc)]),
     "cer_split_bf16": (c_int, [_P, _P, _P, c_int, _P, _P, c_size_t, _P]),
     "cer_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "cer_bn_finalize_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -80,6 +81,8 @@ _SIGNATURES = {
     "cer_add_inplace": (c_int, [_P, _P, c_size_t, _P]),
     "cer_l2norm_rows": (c_int, [_P, _P, c_int, c_int, _P]),
     "cer_maxpool2x2_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
+    "cer_sgd_nesterov_flat": (c_int, [_P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_int, c_int, _P]),
+    "cer_gather_rows": (c_int, [_P, _P, _P, c_int, c_int, c_uint64, _P]),
     "cer_frames_band_rows": (c_int, []),
     "cer_frames_transform": (c_int, [_P, c_int, c_int, c_int, _P, _P, c_int, _P, _P, c_int, c_int, c_int, _P, c_int,
                                      c_int, c_float, c_float, _P, _P, _P]),

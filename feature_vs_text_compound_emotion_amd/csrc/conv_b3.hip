@@ -1377,6 +1377,12 @@ int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st) {
 
 using namespace cer;
 
+extern "C" int cer_conv2d_b3_tile(const cer_conv_desc *d) {
+    if (!d || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return 0;
+    int bm, bn, bk;
+    return conv_b3_tile_dims(d->tile, d->Cout, (long long)d->N * d->Ho * d->Wo, cer_conv_kpad(d->KH, d->KW, d->Cin), bm, bn, bk);
+}
+
 extern "C" int cer_split_bf16(const float *x, const float *scale, const float *shift, int C, uint16_t *hi, uint16_t *lo,
                               size_t n, void *stream) {
     if (!x || !hi || !lo || n == 0 || (n & 3)) return cer_set_error(CER_ERR_INVALID_ARG, "split_bf16: n must be a positive multiple of 4");

@@ -48,7 +48,7 @@ class ClipDataParallel:
         if not self.params:
             raise ValueError("model has no trainable parameter")
         dev = self.params[0].device
-        total = sum(p.numel() for p in self.params)
+        total = (sum(p.numel() for p in self.params) + 3) // 4 * 4  # the fused optimiser works on float4
         self.flat = torch.zeros(total, device=dev, dtype=torch.float32)
         off = 0
         for p in self.params:
@@ -85,6 +85,54 @@ class ClipDataParallel:
             dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.mul_(1.0 / self.world)
 
+    def flatten_parameters(self):
+        """Re-home every trainable parameter in ONE flat fp32 buffer (same order and padding as the gradient bucket) so
+        that the optimiser update is a single launch.  ``p.data`` becomes a view; values are preserved."""
+        if getattr(self, "flat_param", None) is None:
+            self.flat_param = torch.empty_like(self.flat)
+            off = 0
+            for p in self.params:
+                view = self.flat_param[off:off + p.numel()].view_as(p)
+                view.copy_(p.data)
+                p.data = view
+                off += p.numel()
+            self.flat_param[off:].zero_()
+        return self.flat_param
+
     def shard(self, global_batch_indices, rank):
         """Distributed-sampler rule: rank r takes clips r::world of every global batch."""
         return global_batch_indices[rank::self.world]
+
+
+class FlatNesterovSGD:
+    """torch.optim.SGD(momentum, nesterov, weight_decay) of the reference (instantiators.py:74-92) as ONE HIP launch over
+    the flat parameter / gradient / momentum buffers of a ``ClipDataParallel`` (bit-identical arithmetic, tested against
+    torch.optim.SGD).  ``param_groups[0]['lr']`` is what the reference's scheduler mutates (base/scheduler.py:167-197)."""
+
+    def __init__(self, ddp, lr=1e-3, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=True):
+        self.ddp = ddp
+        self.param_groups = [{"params": ddp.params, "lr": lr, "momentum": momentum, "dampening": dampening,
+                              "weight_decay": weight_decay, "nesterov": nesterov}]
+        self.flat_param = ddp.flatten_parameters()
+        self.buf = torch.zeros_like(self.flat_param)
+        self.steps = 0
+
+    def zero_grad(self, set_to_none=False):
+        self.ddp.zero_grad()
+
+    def step(self):
+        from . import ops
+        g = self.param_groups[0]
+        ops.sgd_nesterov_flat(self.flat_param, self.ddp.flat, self.buf, g["lr"], g["momentum"], g["dampening"],
+                              g["weight_decay"], g["nesterov"], first_step=self.steps == 0)
+        self.steps += 1
+
+    def state_dict(self):
+        return {"momentum_buffer": self.buf, "steps": self.steps, "param_groups": [{k: v for k, v in g.items() if k != "params"}
+                                                                                   for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self.buf.copy_(sd["momentum_buffer"])
+        self.steps = int(sd["steps"])
+        for g, h in zip(self.param_groups, sd["param_groups"]):
+            g.update(h)

@@ -14,6 +14,7 @@ base/speech.py:185-251,690-738).  This module fuses that offline stage into the 
 """
 import torch
 
+from . import ops
 from .audio_backbone import AudioBackbone
 from .text_encoder import BertEncoderHIP
 
@@ -75,9 +76,8 @@ class MultimodalFeatureExtractor(torch.nn.Module):
         bsz, s, hd = tok.shape
         mask_cpu = attention_mask_cpu if attention_mask_cpu is not None else attention_mask.cpu()
         plan = self.frame_token_index(mask_cpu, num_frames).to(tok.device)
-        rows = tok.view(bsz * s, hd).index_select(0, plan.clamp(min=0).view(-1)).view(bsz, num_frames, hd)
-        rows = rows * (plan >= 0).unsqueeze(-1).to(rows.dtype)  # frames without a token stay zero
-        return rows.unsqueeze(1).contiguous()
+        rows = ops.gather_rows(tok.view(bsz * s, hd), plan.view(-1).contiguous())  # frames without a token (-1) stay zero
+        return rows.view(bsz, 1, num_frames, hd)
 
     @torch.no_grad()
     def forward(self, frames, pcm_int16, token_ids, attention_mask, attention_mask_cpu=None):

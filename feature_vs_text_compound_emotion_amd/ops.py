@@ -170,6 +170,11 @@ def _dev_bf16(t, name):
         raise ValueError(f"{name}: expected a contiguous bfloat16 GPU tensor")
 
 
+# bench.py sets this to a list to time every bf16x3 conv launch with HIP events on the launch stream:
+# (kernel variant id, algorithmic FLOPs, start event, end event)
+CONV_TRACE = None
+
+
 def conv2d_b3(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bias=None, alpha=None, residual=None,
               res_stride=1, act1=ACT_NONE, act2=ACT_NONE, slope=LEAKY_SLOPE, split_k=1, tile=0, out_f32=False,
               out_split=True, next_affine=None, want_stats=False, bias9=None):
@@ -236,7 +241,13 @@ def conv2d_b3(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bi
         io.stats = res["stats"].data_ptr()
     ws_bytes = lib.cer_conv2d_workspace_bytes(ctypes.byref(d))
     ws = torch.empty((ws_bytes // 4,), device=dev, dtype=torch.float32) if ws_bytes else None
+    if CONV_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(lib.cer_conv2d_run(ctypes.byref(d), ctypes.byref(io), ptr(ws), ws_bytes, current_stream()), "cer_conv2d_run")
+    if CONV_TRACE is not None:
+        e1.record()
+        CONV_TRACE.append((lib.cer_conv2d_b3_tile(ctypes.byref(d)), 2.0 * n * ho * wo * cout * cin * kh * kw, e0, e1))
     return res
 
 
@@ -353,6 +364,25 @@ def fold_input_bn_3x3(w_oihw, scale, shift):
     rows = torch.stack([bt[:, 1:].sum(1), bt.sum(1), bt[:, :2].sum(1)])  # [ry, Cout, kw]: first / inner / last row
     b9 = torch.stack([rows[:, :, 1:].sum(2), rows.sum(2), rows[:, :, :2].sum(2)], 1)  # [ry, rx, Cout]
     return wp, b9.reshape(9, -1).contiguous()
+
+
+def gather_rows(src, index):
+    """out[i] = src[index[i]] (zeros where index < 0); src [R, C] fp32, index int64 on the same device."""
+    _dev_f32(src, "src")
+    if index.dtype != torch.int64 or not index.is_cuda or not index.is_contiguous():
+        raise ValueError("index: expected a contiguous int64 GPU tensor")
+    out = torch.empty((index.numel(), src.shape[1]), device=src.device, dtype=torch.float32)
+    check(_lib.load().cer_gather_rows(ptr(src), ptr(index), ptr(out), index.numel(), src.shape[1], src.shape[0],
+                                      current_stream()), "cer_gather_rows")
+    return out
+
+
+def sgd_nesterov_flat(param, grad, buf, lr, momentum=0.9, dampening=0.0, weight_decay=0.0, nesterov=True, first_step=False):
+    for t, nme in ((param, "param"), (grad, "grad"), (buf, "buf")):
+        _dev_f32(t, nme)
+    check(_lib.load().cer_sgd_nesterov_flat(ptr(param), ptr(grad), ptr(buf), param.numel(), lr, momentum, dampening,
+                                            weight_decay, int(nesterov), int(first_step), current_stream()),
+          "cer_sgd_nesterov_flat")
 
 
 # ------------------------------------------------------------------ trainable tail

@@ -119,6 +119,9 @@ typedef struct cer_conv_io {
 } cer_conv_io;
 
 int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, void *workspace, size_t workspace_bytes, void *stream);
+/* The bf16x3 kernel variant cer_conv2d_run launches for this descriptor (desc.tile, or the automatic choice when it is 0):
+ * 41/42/44/45 = conv_b3_dma16_kernel<128x128 / 128x64 / 64x128 / 64x64>, see csrc/conv_b3.hip.  0 = invalid. */
+int cer_conv2d_b3_tile(const cer_conv_desc *d);
 
 /* v' = v*scale[c]+shift[c] (channels-last, C channels; scale/shift may be NULL) -> (bf16(v'), bf16(v' - bf16(v'))),
  * round-to-nearest-even on both parts. */
@@ -240,6 +243,18 @@ int cer_bn_apply_nhwc_b3(const float *y, const float *scale, const float *shift,
                          const uint16_t *res_hi, const uint16_t *res_lo, const float *res_scale, const float *res_shift,
                          const float *mask, float *out, uint16_t *out_hi, uint16_t *out_lo, float *stats, int N, int Ho,
                          int Wo, int C, int res_stride, int Hr, int Wr, void *stream);
+
+/* Nesterov SGD over flat buffers (reference instantiators.py:74-92: torch.optim.SGD(momentum .9, nesterov, wd 1e-4);
+ * trainer.py:385-391): d = grad + wd*p; buf = first_step ? d : mu*buf + (1-damp)*d; d = nesterov ? d + mu*buf : buf;
+ * p -= lr*d -- torch's _single_tensor_sgd operation by operation, one launch for the whole model.  n % 4 == 0,
+ * 16-byte aligned buffers. */
+int cer_sgd_nesterov_flat(float *param, const float *grad, float *momentum_buf, size_t n, float lr, float momentum,
+                          float dampening, float weight_decay, int nesterov, int first_step, void *stream);
+
+/* out[i][:] = src[index[i]][:], zeros where index[i] < 0 or >= n_src: the token -> frame spreading of the BERT rows
+ * (abaw5_pre_processing/base/speech.py:690-738) and the edge-padded frame indexing of VGGish rows
+ * (base/preprocessing.py:992-1018); the index plan is host logic.  cols % 4 == 0. */
+int cer_gather_rows(const float *src, const int64_t *index, float *out, int n_out, int cols, int64_t n_src, void *stream);
 
 /* ------------------------------------------------------------------------
  * Audio / text encoder front ends and attention.
