@@ -1327,8 +1327,7 @@ int conv_b3_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, 
         case 42: bm = 128; bn = 64; bk = 32; break;
         case 44: bm = 64; bn = 128; bk = 32; break;
         case 45: bm = 64; bn = 64; bk = 32; break;
-        case 46: bm = 256; bn = 256; bk = 32; break;  // 8 waves
-        case 47: bm = 256; bn = 128; bk = 32; break;  // 8 waves
+        case 46: bm = 256; bn = 256; bk = 32; break;  // 8 waves (A/B variant: ties tile 41; 256x128x8 waves and 256x64x4 waves lost 3-18 %)
         case 31: bm = 256; bn = 128; bk = 32; break;
         case 32: bm = 256; bn = 64; bk = 32; break;
         case 33: bm = 128; bn = 128; bk = 32; break;
@@ -1362,7 +1361,6 @@ int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 44: return launch_b3_dma16<64, 128, 1, 4>(a, st);
         case 45: return launch_b3_dma16<64, 64, 2, 2>(a, st);
         case 46: return launch_b3_dma16<256, 256, 2, 4, 8>(a, st);
-        case 47: return launch_b3_dma16<256, 128, 4, 2, 8>(a, st);
         case 31: return launch_b3_win<256, 128, 4, 2>(a, st);
         case 32: return launch_b3_win<256, 64, 8, 1>(a, st);
         case 33: return launch_b3_win<128, 128, 2, 4>(a, st);

@@ -27,7 +27,7 @@ def main():
     extra = dict(kv.split("=", 1) for kv in sys.argv[5:])
     f, nf = total(fetch_dir, "FETCH_SIZE")
     w, nw = total(write_dir, "WRITE_SIZE")
-    res = {"kernel": "cer::conv_b3_kernel + cer::conv_igemm_kernel (all launches of one step)", "steps_profiled": steps,
+    res = {"kernel": "cer::conv_b3_dma16_kernel + cer::conv_igemm_kernel (all conv launches of one step)", "steps_profiled": steps,
            "launches_per_step": nf / steps,
            "fetch_bytes_per_step": 2.0 * f * 1024 / steps, "write_bytes_per_step": w * 1024 / steps,
            "hbm_bytes_per_step": (2.0 * f + w) * 1024 / steps,
