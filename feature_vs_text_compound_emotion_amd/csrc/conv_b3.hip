@@ -895,6 +895,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_b3_dma16_kernel
     static_for<TP>([&](auto B) {
         constexpr int b = decltype(B)::v;
         const int m = m0 + (wp * TP + b) * 16 + l15;
+        // the pixel's bias row is chosen ONCE per pixel tile (two integer divisions), not per 4-cout store
+        const float *brow = (p.bias9 && m < p.M) ? p.bias9 + (size_t)bias9_case(p, m) * p.Cout : p.bias;
         static_for<TC>([&](auto A) {
             constexpr int a = decltype(A)::v;
             const int c = c0 + (wc * TC + a) * 16 + 4 * kg;
@@ -910,7 +912,7 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_b3_dma16_kernel
                             if (c + e < p.Cout) dst[e] = v[e];
                     }
                 } else {
-                    epilogue_store4(p, m, c, v);
+                    epilogue_store4(p, m, c, v, brow);
                 }
             }
         });

@@ -71,7 +71,23 @@ __device__ __forceinline__ float act_apply(float v, int act, float a, float slop
 
 // Shared epilogue for the fused path and the split-K reducer.
 // v: 4 consecutive couts starting at c for output row m.
+// Row / column state of output pixel m for bias9 (0 first, 2 last, 1 inner): index 3*ry + rx.
+__device__ __forceinline__ int bias9_case(const ConvArgs &p, int m) {
+    const int hw = p.Ho * p.Wo;
+    const int r = m % hw;
+    const int ho = r / p.Wo, wo = r - ho * p.Wo;
+    const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
+    return 3 * ry + rx;
+}
+
+// bias_row: the bias vector to use for this pixel (p.bias, or the caller's pre-selected bias9 row)
+__device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c, float v[4], const float *bias);
+
 __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c, float v[4]) {
+    epilogue_store4(p, m, c, v, p.bias9 ? p.bias9 + (size_t)bias9_case(p, m) * p.Cout : p.bias);
+}
+
+__device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c, float v[4], const float *bias) {
     const bool vec = ((p.Cout & 3) == 0);
     size_t roff = 0;
     if (p.res || p.res_hi) {
@@ -86,14 +102,6 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c,
     }
     const size_t yoff = (size_t)m * p.y_ld + c;
     const size_t doff = (size_t)m * p.Cout + c;  // dense offset (mask, aux)
-    const float *bias = p.bias;
-    if (p.bias9) {
-        const int hw = p.Ho * p.Wo;
-        const int r = m % hw;
-        const int ho = r / p.Wo, wo = r - ho * p.Wo;
-        const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
-        bias = p.bias9 + (size_t)(3 * ry + rx) * p.Cout;
-    }
     if (vec && ((p.y_ld & 3) == 0) && c + 3 < p.Cout) {
         float4 b = bias ? *reinterpret_cast<const float4 *>(bias + c) : make_float4(0, 0, 0, 0);
         float4 a = (p.act1 == CER_ACT_PRELU) ? *reinterpret_cast<const float4 *>(p.alpha + c) : make_float4(0, 0, 0, 0);

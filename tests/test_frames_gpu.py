@@ -65,3 +65,32 @@ def test_cpu_tensor_is_rejected():
     from feature_vs_text_compound_emotion_amd.frames import FrameTransform
     with pytest.raises(RuntimeError, match="no CPU fallback"):
         FrameTransform()(torch.zeros(1, 1, 8, 8, 3, dtype=torch.uint8))
+
+
+def test_trial_dataset_batch_through_the_gpu_transform(tmp_path):
+    """.npy trials -> TrialDataset (raw uint8 video) -> collate_to_device -> FrameTransform == the CPU oracle."""
+    from feature_vs_text_compound_emotion_amd.frames import FrameTransform
+    from feature_vs_text_compound_emotion_amd.trial_dataset import (TrialDataset, calculate_mean_std, collate_to_device,
+                                                                      windowed_trial_list)
+    rng = np.random.default_rng(0)
+    trials = []
+    for name, n in (("a", 9), ("b", 3)):
+        d = tmp_path / name
+        d.mkdir()
+        np.save(d / "video.npy", rng.integers(0, 256, (n, 64, 64, 3), dtype=np.uint8))
+        np.save(d / "vggish.npy", rng.normal(size=(n, 128)).astype(np.float32))
+        np.save(d / "EXPR_continuous_label.npy", rng.integers(0, 7, n))
+        trials.append([str(d), name, n])
+    mods = ["video", "vggish", "EXPR_continuous_label"]
+    data = windowed_trial_list(trials, 4, 3)
+    ds = TrialDataset(data, mods, {m: 1 for m in mods}, {"video": (64, 64, 3), "vggish": (128,), "EXPR_continuous_label": (1,)},
+                      4, "train", mean_std=calculate_mean_std(data, ("vggish",)))
+    batch = [ds[i] for i in range(len(ds))]
+    ft = FrameTransform(48, 40, train=True)
+    cx = ft.draw(len(batch))
+    x, names, lengths, index = collate_to_device(batch, "cuda", ft, crop_xyf=cx)
+    assert tuple(x["video"].shape) == (len(batch), 4, 3, 40, 40) and tuple(x["vggish"].shape) == (len(batch), 1, 4, 128)
+    assert tuple(x["EXPR_continuous_label"].shape) == (len(batch), 4, 1) and names[-1] == "b"
+    for i, b in enumerate(batch):
+        ref = frames_transform(b[0]["video"].numpy(), 48, 40, int(cx[i, 0]), int(cx[i, 1]), bool(cx[i, 2]))
+        assert np.array_equal(x["video"][i].cpu().numpy(), ref)
