@@ -80,6 +80,7 @@ _SIGNATURES = {
     "cer_attention_bwd": (c_int, [_P] * 11 + [c_int] * 5 + [_P] * 8 + [c_float, _P]),
     "cer_add_inplace": (c_int, [_P, _P, c_size_t, _P]),
     "cer_l2norm_rows": (c_int, [_P, _P, c_int, c_int, _P]),
+    "cer_l2norm_rows_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P]),
     "cer_maxpool2x2_nhwc": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P]),
     "cer_sgd_nesterov_flat": (c_int, [_P, _P, _P, c_size_t, c_float, c_float, c_float, c_float, c_int, c_int, _P]),
     "cer_gather_rows": (c_int, [_P, _P, _P, c_int, c_int, c_uint64, _P]),

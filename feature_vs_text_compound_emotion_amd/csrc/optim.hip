@@ -47,9 +47,37 @@ __global__ void gather_rows_kernel(const float4 *__restrict__ src, const int64_t
     out[i] = (s >= 0 && s < n_src) ? src[(size_t)s * cols4 + c] : make_float4(0, 0, 0, 0);
 }
 
+// y = x / ||x||  ->  dx = (dy - y * (y . dy)) / ||x||   (one wave per row; reference models/arcface_model.py:17-20)
+__global__ void l2norm_rows_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ dx,
+                                       int rows, int cols) {
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * cols, *gr = dy + (size_t)row * cols;
+    float ss = 0.f, dot = 0.f;
+    for (int c = lane; c < cols; c += 64) {
+        ss += xr[c] * xr[c];
+        dot += xr[c] * gr[c];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        ss += __shfl_xor(ss, o);
+        dot += __shfl_xor(dot, o);
+    }
+    const float inv = 1.f / sqrtf(ss);
+    const float k = dot * inv * inv * inv;  // (y . dy) / ||x|| * (1/||x||) with y = x/||x||
+    for (int c = lane; c < cols; c += 64) dx[(size_t)row * cols + c] = gr[c] * inv - xr[c] * k;
+}
+
 }  // namespace cer
 
 using namespace cer;
+
+extern "C" int cer_l2norm_rows_bwd(const float *dy, const float *x, float *dx, int rows, int cols, void *stream) {
+    if (!dy || !x || !dx || rows <= 0 || cols <= 0) return cer_set_error(CER_ERR_INVALID_ARG, "l2norm_rows_bwd: bad argument");
+    CER_LAUNCH(l2norm_rows_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, dy, x, dx, rows, cols);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
 
 extern "C" int cer_sgd_nesterov_flat(float *param, const float *grad, float *momentum_buf, size_t n, float lr, float momentum,
                                      float dampening, float weight_decay, int nesterov, int first_step, void *stream) {

@@ -274,6 +274,16 @@ def l2norm_rows(x):
     return y
 
 
+def l2norm_rows_bwd(dy, x):
+    """Gradient of ``l2norm_rows`` w.r.t. its input ``x`` (the un-normalised rows)."""
+    _dev_f32(dy, "dy")
+    _dev_f32(x, "x")
+    dx = torch.empty_like(x)
+    check(_lib.load().cer_l2norm_rows_bwd(ptr(dy), ptr(x), ptr(dx), x.shape[0], x.shape[1], current_stream()),
+          "cer_l2norm_rows_bwd")
+    return dx
+
+
 def maxpool2x2_nhwc(x):
     _dev_f32(x, "x")
     n, h, w, c = x.shape

@@ -44,6 +44,46 @@ class _Flatten(nn.Module):
     pass
 
 
+class _ReleasedHead(torch.autograd.Function):
+    """Forward + backward of the encoder's output layer in train mode, for the FIRST group of the reference's gradual
+    release (base/parameter_control.py:55-103: parameters 4..9 of the visual encoder = ``output_layer``:
+    BatchNorm2d(512) -> Dropout(0.4) -> flatten (c,h,w) -> Linear -> BatchNorm1d(512), then ``l2_norm``;
+    arcface_model.py:133-137,147-151).  The body below it stays frozen, so no data gradient leaves this function.
+    Everything runs on the exact-fp32 kernels (row BatchNorm fwd/bwd, igemm GEMMs, TN weight-gradient GEMM)."""
+
+    @staticmethod
+    def forward(ctx, y, mask, bn2, fc, bn1, w2, b2, wfc, bfc, w1, b1):
+        n, h, w, c = y.shape
+        rows = y.view(n * h * w, c)
+        o2, sm2, si2 = ops.bn_rows_fwd(rows, w2.detach(), b2.detach(), bn2.running_mean, bn2.running_var, True, bn2.eps,
+                                       bn2.momentum)
+        hfeat = ops.act_mask_bwd(o2, o2, mask.view(n * h * w, c), slope=1.0) if mask is not None else o2  # o2 * mask
+        k = h * w * c
+        whwc = wfc.detach().view(wfc.shape[0], c, h * w).permute(0, 2, 1).contiguous().view(wfc.shape[0], k)  # (c,h,w)->(h,w,c)
+        e = ops.linear(hfeat.view(n, k), whwc, bias=bfc.detach(), split_k=max(1, min(k // 32, 192 // ((n + 127) // 128))))
+        e2, sm1, si1 = ops.bn_rows_fwd(e, w1.detach(), b1.detach(), bn1.running_mean, bn1.running_var, True, bn1.eps,
+                                       bn1.momentum)
+        ctx.save_for_backward(rows, mask, hfeat, e, e2, sm2, si2, sm1, si1, whwc, w2.detach(), w1.detach())
+        ctx.dims = (n, h, w, c)
+        return ops.l2norm_rows(e2)
+
+    @staticmethod
+    def backward(ctx, demb):
+        rows, mask, hfeat, e, e2, sm2, si2, sm1, si1, whwc, w2, w1 = ctx.saved_tensors
+        n, h, w, c = ctx.dims
+        k = h * w * c
+        de2 = ops.l2norm_rows_bwd(demb.contiguous(), e2)
+        de, dw1, db1 = ops.bn_rows_bwd(de2, e, sm1, si1, w1)
+        dwhwc = ops.conv1d_wgrad(de, hfeat.view(n, k), n, 1, 1).view(-1, h * w, c)      # dW[o][(h,w,c)] = de^T hfeat
+        dwfc = dwhwc.permute(0, 2, 1).reshape(-1, k)                                     # back to the (c,h,w) flatten order
+        dbfc = ops.col_sum(de)
+        dh = ops.linear(de, whwc.t().contiguous())                                       # [n, k] = de @ W
+        do2 = ops.act_mask_bwd(dh.view(n * h * w, c), dh.view(n * h * w, c), mask.view(n * h * w, c), slope=1.0) \
+            if mask is not None else dh.view(n * h * w, c)
+        _, dw2, db2 = ops.bn_rows_bwd(do2, rows, sm2, si2, w2)
+        return None, None, None, None, None, dw2, db2, dwfc, dbfc, dw1, db1
+
+
 class IR50(nn.Module):
     """``Backbone(num_layers=50, mode='ir')`` with an h x w output head."""
 
@@ -286,12 +326,14 @@ class IR50(nn.Module):
         nn_, h, w, c = y.shape
         if h != self.head_hw or w != self.head_hw:
             raise RuntimeError(f"IR50 head was built for {self.head_hw}x{self.head_hw} feature maps but got {h}x{w}")
-        s0, t0 = self._finalize(xst, y.numel() // c, self.output_layer[0])
         p_drop = self.output_layer[1].p
         if head_mask is None and p_drop > 0:
             self._dropout_calls += 1
             head_mask = ops.dropout_mask(tuple(y.shape), p_drop, 0x1f50 + self.dropout_seed, self._dropout_calls * y.numel(),
                                          y.device)
+        if self._head_released():
+            return self._released_head(y, head_mask)
+        s0, t0 = self._finalize(xst, y.numel() // c, self.output_layer[0])
         hfeat = ops.bn_apply_nhwc_b3(y, s0, t0, mask=head_mask)["split"]
         k = h * w * c
         fc, bn1 = self.output_layer[3], self.output_layer[4]
@@ -302,6 +344,29 @@ class IR50(nn.Module):
         torch._foreach_add_([m.num_batches_tracked for m in self.modules()
                              if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d))], 1)
         return ops.l2norm_rows(e)
+
+    # ------------------------------------------------------------------ gradual release (first group: the head)
+    def _head_released(self):
+        """base/parameter_control.py:85-96 flips ``requires_grad`` of parameter groups of the visual encoder; the first
+        group (indices 4..9) is exactly ``output_layer``.  The later groups reach into the body, whose backward
+        (IR-50 dgrad / wgrad) is not built: fail loudly rather than silently train nothing."""
+        if not torch.is_grad_enabled():
+            return False
+        head = [p.requires_grad for p in self.output_layer.parameters()]
+        rest = [p.requires_grad for m in (self.input_layer, self.body) for p in m.parameters()]
+        if any(rest):
+            raise NotImplementedError("gradual release beyond the output layer needs the IR-50 body backward, which is not "
+                                      "built (SURVEY 8f rank 2): only base/parameter_control.py's first group is supported")
+        if any(head) and not all(head):
+            raise NotImplementedError("release the whole output layer (parameters 4..9) or nothing")
+        return all(head)
+
+    def _released_head(self, y, head_mask):
+        bn2, fc, bn1 = self.output_layer[0], self.output_layer[3], self.output_layer[4]
+        out = _ReleasedHead.apply(y, head_mask, bn2, fc, bn1, bn2.weight, bn2.bias, fc.weight, fc.bias, bn1.weight, bn1.bias)
+        torch._foreach_add_([m.num_batches_tracked for m in self.modules()
+                             if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d))], 1)
+        return out
 
     # ------------------------------------------------------------------ forward
     def _head_split_k(self, n, k):

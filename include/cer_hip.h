@@ -139,6 +139,10 @@ int cer_pack_conv_weight(const float *w_oihw, const float *out_scale, float *w_p
 /* rows x / ||x||_2, no epsilon (reference models/arcface_model.py:17-20). */
 int cer_l2norm_rows(const float *x, float *y, int rows, int cols, void *stream);
 
+/* Backward of cer_l2norm_rows: x is the forward INPUT; dx = (dy - y (y.dy)) / ||x|| with y = x/||x||.  Used when the
+ * encoder head is released for training (reference base/parameter_control.py:55-103, first release group). */
+int cer_l2norm_rows_bwd(const float *dy, const float *x, float *dx, int rows, int cols, void *stream);
+
 /* max-pool 2x2 stride 2 on NHWC (reference models/backbone.py:45-46). */
 int cer_maxpool2x2_nhwc(const float *x, float *y, int N, int H, int W, int C, void *stream);
 
