@@ -45,7 +45,9 @@ def build(force=False, verbose=True):
         objs.append(obj)
         with open(src, "rb") as fh:
             sh = hashlib.sha256(fh.read())
-        for hdr in ("cer_internal.h", os.path.join("..", "..", "include", "cer_hip.h")):
+        # every header a translation unit may include: all of csrc/*.h plus the public ABI header
+        hdrs = sorted(h for h in os.listdir(CSRC) if h.endswith(".h")) + [os.path.join("..", "..", "include", "cer_hip.h")]
+        for hdr in hdrs:
             with open(os.path.join(CSRC, hdr), "rb") as fh:
                 sh.update(fh.read())
         sh.update(" ".join(FLAGS).encode())
