@@ -548,6 +548,12 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
     if (vec || b3) {
         // the staging path addresses x and w as scalar base + 32-bit per-thread byte offset
         if (d->KH * d->KW > 32) return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d: more than 32 filter taps");
+        // the per-row offsets are UNSIGNED distances from the tile's first row: output pixels must map to non-decreasing
+        // input addresses, also across row and image boundaries (an out_hw larger than the natural one breaks that:
+        // a wrapped offset would read 4 GiB away)
+        if (d->Wo > d->W / d->stride + 1 ||
+            (long long)d->H * d->W < (long long)(d->Ho - 1) * d->stride * d->W + (long long)(d->Wo - 1) * d->stride)
+            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d: the output grid outruns the input (Ho/Wo too large for H/W and stride)");
         const long long span_px = (long long)bm * d->stride * d->stride + 2ll * d->H * d->W + (long long)d->W * d->stride + 2;
         if (span_px * a.x_ld * esz >= (1ll << 31) || (long long)bn * a.Kpad * esz >= (1ll << 32))
             return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d: tile footprint exceeds 32-bit staging offsets");

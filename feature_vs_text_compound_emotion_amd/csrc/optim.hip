@@ -47,6 +47,27 @@ __global__ void gather_rows_kernel(const float4 *__restrict__ src, const int64_t
     out[i] = (s >= 0 && s < n_src) ? src[(size_t)s * cols4 + c] : make_float4(0, 0, 0, 0);
 }
 
+// channels-last PReLU with per-channel slopes (arcface_model.py:54): y = x > 0 ? x : alpha[c] * x
+__global__ void prelu_fwd_kernel(const float4 *__restrict__ x, const float *__restrict__ alpha, float4 *__restrict__ y, size_t n4,
+                                 int C4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 v = x[i], a = *reinterpret_cast<const float4 *>(alpha + (i % C4) * 4);
+    y[i] = make_float4(v.x > 0.f ? v.x : a.x * v.x, v.y > 0.f ? v.y : a.y * v.y, v.z > 0.f ? v.z : a.z * v.z,
+                       v.w > 0.f ? v.w : a.w * v.w);
+}
+// torch's prelu backward: dx = x > 0 ? dy : alpha[c]*dy; the slope gradient is the column sum of t = x > 0 ? 0 : x*dy
+__global__ void prelu_bwd_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ x, const float *__restrict__ alpha,
+                                 float4 *__restrict__ dx, float4 *__restrict__ t, size_t n4, int C4) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const float4 g = dy[i], v = x[i], a = *reinterpret_cast<const float4 *>(alpha + (i % C4) * 4);
+    dx[i] = make_float4(v.x > 0.f ? g.x : a.x * g.x, v.y > 0.f ? g.y : a.y * g.y, v.z > 0.f ? g.z : a.z * g.z,
+                        v.w > 0.f ? g.w : a.w * g.w);
+    t[i] = make_float4(v.x > 0.f ? 0.f : v.x * g.x, v.y > 0.f ? 0.f : v.y * g.y, v.z > 0.f ? 0.f : v.z * g.z,
+                       v.w > 0.f ? 0.f : v.w * g.w);
+}
+
 // y = x / ||x||  ->  dx = (dy - y * (y . dy)) / ||x||   (one wave per row; reference models/arcface_model.py:17-20)
 __global__ void l2norm_rows_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x, float *__restrict__ dx,
                                        int rows, int cols) {
@@ -99,6 +120,26 @@ extern "C" int cer_gather_rows(const float *src, const int64_t *index, float *ou
         return cer_set_error(CER_ERR_INVALID_ARG, "gather_rows: needs src, index, out and cols % 4 == 0");
     CER_LAUNCH(gather_rows_kernel, dim3(cer_blocks((size_t)n_out * (cols / 4), 256)), dim3(256), 0, (hipStream_t)stream,
                (const float4 *)src, index, (float4 *)out, n_out, cols / 4, n_src);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+extern "C" int cer_prelu_fwd(const float *x, const float *alpha, float *y, size_t rows, int C, void *stream) {
+    if (!x || !alpha || !y || rows == 0 || C <= 0 || (C & 3)) return cer_set_error(CER_ERR_INVALID_ARG, "prelu_fwd: C % 4 == 0");
+    const size_t n4 = rows * (C / 4);
+    CER_LAUNCH(prelu_fwd_kernel, dim3(cer_blocks(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)x, alpha, (float4 *)y,
+               n4, C / 4);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+extern "C" int cer_prelu_bwd(const float *dy, const float *x, const float *alpha, float *dx, float *dalpha_terms, size_t rows,
+                             int C, void *stream) {
+    if (!dy || !x || !alpha || !dx || !dalpha_terms || rows == 0 || C <= 0 || (C & 3))
+        return cer_set_error(CER_ERR_INVALID_ARG, "prelu_bwd: C % 4 == 0");
+    const size_t n4 = rows * (C / 4);
+    CER_LAUNCH(prelu_bwd_kernel, dim3(cer_blocks(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)dy, (const float4 *)x,
+               alpha, (float4 *)dx, (float4 *)dalpha_terms, n4, C / 4);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }

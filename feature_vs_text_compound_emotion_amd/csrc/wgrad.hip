@@ -19,6 +19,9 @@ struct WgradArgs {
     const float *dz, *x;
     float *dw;
     int R, L, Cout, Cin, k, dil, dz_ld, x_ld;
+    // 2-D mode (H > 0): row r = output pixel (n, ho, wo), tap = kh*KW + kw, source pixel
+    // (n, ho*stride - pad_t + kh, wo*stride - pad_l + kw) of the NHWC input, zero outside the image
+    int H, W, Ho, Wo, KW, stride, pad_t, pad_l;
 };
 
 constexpr int WG_ROWS = 32;  // reduction rows per step
@@ -33,6 +36,7 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs p) {
     const int half = lane >> 5, l31 = lane & 31;
     const int co0 = blockIdx.x * WG_T, ci0 = blockIdx.y * WG_T, tap = blockIdx.z;
     const int shift = (p.k - 1 - tap) * p.dil;
+    const int kh2 = p.H > 0 ? tap / p.KW : 0, kw2 = p.H > 0 ? tap - kh2 * p.KW : 0;
 
     // staging: 32 rows x 16 float4 per operand = 512 float4 -> 2 per thread per operand
     const int srow = tid >> 4, scol = (tid & 15) * 4;
@@ -53,9 +57,18 @@ __global__ __launch_bounds__(256) void conv1d_wgrad_kernel(WgradArgs p) {
                     if (co + 2 < p.Cout) a.z = ap[2];
                     if (co + 3 < p.Cout) a.w = ap[3];
                 }
-                const int t = r % p.L;
-                if (t >= shift) {
-                    const float *bp = p.x + (size_t)(r - shift) * p.x_ld + ci;
+                long long src = -1;
+                if (p.H > 0) {
+                    const int hw = p.Ho * p.Wo;
+                    const int n = r / hw, q = r - n * hw;
+                    const int ho = q / p.Wo, wo = q - ho * p.Wo;
+                    const int hi = ho * p.stride - p.pad_t + kh2, wi = wo * p.stride - p.pad_l + kw2;
+                    if ((unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) src = ((long long)n * p.H + hi) * p.W + wi;
+                } else if (r % p.L >= shift) {
+                    src = r - shift;
+                }
+                if (src >= 0) {
+                    const float *bp = p.x + (size_t)src * p.x_ld + ci;
                     if (ci + 3 < p.Cin && ((p.x_ld & 3) == 0)) {
                         b = *reinterpret_cast<const float4 *>(bp);
                     } else {
@@ -118,8 +131,20 @@ extern "C" int cer_conv1d_wgrad(const float *dz, int dz_ld, const float *x, int 
     if (!dz || !x || !dw || R <= 0 || L <= 0 || Cout <= 0 || Cin <= 0 || k <= 0 || dil <= 0 || dz_ld < Cout ||
         x_ld < Cin || (R % L) != 0)
         return cer_set_error(CER_ERR_INVALID_ARG, "conv1d_wgrad: bad argument (R must be a multiple of L)");
-    WgradArgs a{dz, x, dw, R, L, Cout, Cin, k, dil, dz_ld, x_ld};
+    WgradArgs a{dz, x, dw, R, L, Cout, Cin, k, dil, dz_ld, x_ld, 0, 0, 0, 0, 0, 0, 0, 0};
     dim3 grid((Cout + WG_T - 1) / WG_T, (Cin + WG_T - 1) / WG_T, k);
+    CER_LAUNCH(conv1d_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+extern "C" int cer_conv2d_wgrad(const float *dz, const float *x, float *dw, int N, int H, int W, int Ho, int Wo, int Cout,
+                                int Cin, int KH, int KW, int stride, int pad_t, int pad_l, void *stream) {
+    if (!dz || !x || !dw || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 ||
+        stride <= 0 || pad_t < 0 || pad_l < 0 || (long long)N * Ho * Wo >= (1ll << 31) || KH * KW > 65535)
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_wgrad: bad argument");
+    WgradArgs a{dz, x, dw, N * Ho * Wo, 1, Cout, Cin, KH * KW, 1, Cout, Cin, H, W, Ho, Wo, KW, stride, pad_t, pad_l};
+    dim3 grid((Cout + WG_T - 1) / WG_T, (Cin + WG_T - 1) / WG_T, KH * KW);
     CER_LAUNCH(conv1d_wgrad_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;

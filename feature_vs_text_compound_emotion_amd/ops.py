@@ -274,6 +274,38 @@ def l2norm_rows(x):
     return y
 
 
+def conv2d_wgrad(dz, x, kh, kw, stride=1, pad=(0, 0)):
+    """dW [Cout,Cin,KH,KW] (torch layout) from dz [N,Ho,Wo,Cout] and the conv input x [N,H,W,Cin] (both dense NHWC)."""
+    _dev_f32(dz, "dz")
+    _dev_f32(x, "x")
+    n, ho, wo, cout = dz.shape
+    _, h, w, cin = x.shape
+    dw = _empty((cout, cin, kh, kw), dz)
+    check(_lib.load().cer_conv2d_wgrad(ptr(dz), ptr(x), ptr(dw), n, h, w, ho, wo, cout, cin, kh, kw, stride, pad[0], pad[1],
+                                       current_stream()), "cer_conv2d_wgrad")
+    return dw
+
+
+def prelu_fwd(x, alpha):
+    _dev_f32(x, "x")
+    _dev_f32(alpha, "alpha")
+    y = torch.empty_like(x)
+    check(_lib.load().cer_prelu_fwd(ptr(x), ptr(alpha), ptr(y), x.numel() // x.shape[-1], x.shape[-1], current_stream()),
+          "cer_prelu_fwd")
+    return y
+
+
+def prelu_bwd(dy, x, alpha):
+    """-> (dx, dalpha): torch's PReLU backward for channels-last tensors."""
+    for t, nme in ((dy, "dy"), (x, "x"), (alpha, "alpha")):
+        _dev_f32(t, nme)
+    dx, terms = torch.empty_like(x), torch.empty_like(x)
+    c = x.shape[-1]
+    check(_lib.load().cer_prelu_bwd(ptr(dy), ptr(x), ptr(alpha), ptr(dx), ptr(terms), x.numel() // c, c, current_stream()),
+          "cer_prelu_bwd")
+    return dx, col_sum(terms.view(-1, c))
+
+
 def l2norm_rows_bwd(dy, x):
     """Gradient of ``l2norm_rows`` w.r.t. its input ``x`` (the un-normalised rows)."""
     _dev_f32(dy, "dy")

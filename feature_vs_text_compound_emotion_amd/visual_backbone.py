@@ -44,6 +44,88 @@ class _Flatten(nn.Module):
     pass
 
 
+def _conv_dgrad(dy, w_oihw, stride, pad, in_hw):
+    """Data gradient of a conv (fp32 kernels): the forward kernel on the transposed + flipped filter with padding
+    k-1-pad; for stride > 1 the output gradient is first spread onto the stride grid of a zero image sized so that this
+    is a NATURAL convolution geometry (H_up + 2(k-1-pad) - k + 1 == H_in)."""
+    kh, kw = w_oihw.shape[2], w_oihw.shape[3]
+    wt = ops.pack_conv_weight(w_oihw.contiguous(), flip=True, transpose=True)
+    n, ho, wo, c = dy.shape
+    hu, wu = in_hw[0] - kh + 1 + 2 * pad, in_hw[1] - kw + 1 + 2 * pad
+    if stride > 1 or (hu, wu) != (ho, wo):
+        up = torch.zeros((n, hu, wu, c), device=dy.device, dtype=dy.dtype)
+        up[:, :(ho - 1) * stride + 1:stride, :(wo - 1) * stride + 1:stride] = dy
+        dy = up
+    return ops.conv2d(dy, wt, kh, kw, pad=(kh - 1 - pad, kw - 1 - pad))
+
+
+class _ReleasedUnit(torch.autograd.Function):
+    """One bottleneck_IR unit (arcface_model.py:44-60) in train mode WITH its backward, for the body groups of the
+    reference's gradual release (base/parameter_control.py:55-103: stage 4, then half of stage 3).  Exact-fp32 kernels:
+    row BatchNorm fwd/bwd, implicit-GEMM conv (forward and, on the transposed/flipped filter, data gradient), the 2-D
+    TN weight-gradient GEMM, PReLU fwd/bwd."""
+
+    @staticmethod
+    def forward(ctx, x, u, g1, b1, w1, a1, w2, g2, b2, ws, gs, bs):
+        n, h, w, cin = x.shape
+        bn1, bn2, s = u.res_layer[0], u.res_layer[4], u.stride
+        xb, sm1, si1 = ops.bn_rows_fwd(x.view(-1, cin), g1.detach(), b1.detach(), bn1.running_mean, bn1.running_var, True,
+                                       bn1.eps, bn1.momentum)
+        xb = xb.view(n, h, w, cin)
+        z1 = ops.conv2d(xb, ops.pack_conv_weight(w1.detach().contiguous()), 3, 3, pad=(1, 1))
+        t1 = ops.prelu_fwd(z1, a1.detach().contiguous())
+        z2 = ops.conv2d(t1, ops.pack_conv_weight(w2.detach().contiguous()), 3, 3, stride=s, pad=(1, 1))
+        _, ho, wo, depth = z2.shape
+        out, sm2, si2 = ops.bn_rows_fwd(z2.view(-1, depth), g2.detach(), b2.detach(), bn2.running_mean, bn2.running_var, True,
+                                        bn2.eps, bn2.momentum)
+        out = out.view(n, ho, wo, depth)
+        zs = sms = sis = None
+        if ws is not None:
+            bns = u.shortcut_layer[1]
+            zs = ops.conv2d(x, ops.pack_conv_weight(ws.detach().contiguous()), 1, 1, stride=s)
+            sc, sms, sis = ops.bn_rows_fwd(zs.view(-1, depth), gs.detach(), bs.detach(), bns.running_mean, bns.running_var, True,
+                                           bns.eps, bns.momentum)
+            ops.add_inplace(out, sc.view(n, ho, wo, depth))
+        else:
+            ops.add_inplace(out, x[:, ::s, ::s].contiguous() if s > 1 else x)  # MaxPool2d(1, s) == subsample
+        ctx.save_for_backward(x, xb, z1, t1, z2, sm1, si1, sm2, si2, zs, sms, sis, g1.detach(), w1.detach(), a1.detach(),
+                              w2.detach(), g2.detach(), ws.detach() if ws is not None else None,
+                              gs.detach() if gs is not None else None)
+        ctx.stride = s
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, xb, z1, t1, z2, sm1, si1, sm2, si2, zs, sms, sis, g1, w1, a1, w2, g2, ws, gs = ctx.saved_tensors
+        s = ctx.stride
+        n, h, w, cin = x.shape
+        _, ho, wo, depth = z2.shape
+        dout = dout.contiguous()
+        dz2, dg2, db2 = ops.bn_rows_bwd(dout.view(-1, depth), z2.view(-1, depth), sm2, si2, g2)
+        dz2 = dz2.view(n, ho, wo, depth)
+        dw2 = ops.conv2d_wgrad(dz2, t1, 3, 3, stride=s, pad=(1, 1))
+        dt1 = _conv_dgrad(dz2, w2, s, 1, (h, w))
+        dz1, da1 = ops.prelu_bwd(dt1, z1, a1.contiguous())
+        dw1 = ops.conv2d_wgrad(dz1, xb, 3, 3, stride=1, pad=(1, 1))
+        need_dx = ctx.needs_input_grad[0]
+        dxb = _conv_dgrad(dz1, w1, 1, 1, (h, w))
+        dx, dg1, db1 = ops.bn_rows_bwd(dxb.view(-1, cin), x.view(-1, cin), sm1, si1, g1)
+        dx = dx.view(n, h, w, cin)
+        dws = dgs = dbs = None
+        if ws is not None:
+            dzs, dgs, dbs = ops.bn_rows_bwd(dout.view(-1, depth), zs.view(-1, depth), sms, sis, gs)
+            dzs = dzs.view(n, ho, wo, depth)
+            dws = ops.conv2d_wgrad(dzs, x, 1, 1, stride=s, pad=(0, 0))
+            if need_dx:
+                ops.add_inplace(dx, _conv_dgrad(dzs, ws, s, 0, (h, w)))
+        elif need_dx:
+            if s > 1:
+                dx[:, ::s, ::s] += dout
+            else:
+                ops.add_inplace(dx, dout)
+        return (dx if need_dx else None), None, dg1, db1, dw1, da1, dw2, dg2, db2, dws, dgs, dbs
+
+
 class _ReleasedHead(torch.autograd.Function):
     """Forward + backward of the encoder's output layer in train mode, for the FIRST group of the reference's gradual
     release (base/parameter_control.py:55-103: parameters 4..9 of the visual encoder = ``output_layer``:
@@ -80,8 +162,9 @@ class _ReleasedHead(torch.autograd.Function):
         dh = ops.linear(de, whwc.t().contiguous())                                       # [n, k] = de @ W
         do2 = ops.act_mask_bwd(dh.view(n * h * w, c), dh.view(n * h * w, c), mask.view(n * h * w, c), slope=1.0) \
             if mask is not None else dh.view(n * h * w, c)
-        _, dw2, db2 = ops.bn_rows_bwd(do2, rows, sm2, si2, w2)
-        return None, None, None, None, None, dw2, db2, dwfc, dbfc, dw1, db1
+        dy, dw2, db2 = ops.bn_rows_bwd(do2, rows, sm2, si2, w2)
+        dy = dy.view(n, h, w, c) if ctx.needs_input_grad[0] else None  # only when body units below are released too
+        return dy, None, None, None, None, dw2, db2, dwfc, dbfc, dw1, db1
 
 
 class IR50(nn.Module):
@@ -300,9 +383,14 @@ class IR50(nn.Module):
         r = ops.bn_apply_nhwc_b3(y0, s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True)
         ys, xst = r["split"], r["stats"]
         del y0, r
+        plan = self._release_plan()
+        first_released = len(P["units"]) if plan is None else plan
         y = None
         for i, (u, d) in enumerate(zip(self.body, P["units"])):
-            last = i + 1 == len(P["units"])
+            if i >= first_released:  # released for training: exact-fp32 path with a backward
+                y = self._released_unit(u, y)
+                continue
+            last = i + 1 == first_released  # the next consumer (released unit or head) wants fp32
             s1, t1 = self._finalize(xst, ys.hi.numel() // u.cin, u.res_layer[0])
             w1, b9 = ops.fold_input_bn_3x3(u.res_layer[1].weight.detach(), s1, t1)
             tt = ops.conv2d_b3(ys, ops.split_bf16(w1), 3, 3, pad=(1, 1), alpha=u.res_layer[2].weight.detach(),
@@ -331,7 +419,7 @@ class IR50(nn.Module):
             self._dropout_calls += 1
             head_mask = ops.dropout_mask(tuple(y.shape), p_drop, 0x1f50 + self.dropout_seed, self._dropout_calls * y.numel(),
                                          y.device)
-        if self._head_released():
+        if plan is not None:
             return self._released_head(y, head_mask)
         s0, t0 = self._finalize(xst, y.numel() // c, self.output_layer[0])
         hfeat = ops.bn_apply_nhwc_b3(y, s0, t0, mask=head_mask)["split"]
@@ -346,20 +434,42 @@ class IR50(nn.Module):
         return ops.l2norm_rows(e)
 
     # ------------------------------------------------------------------ gradual release (first group: the head)
-    def _head_released(self):
-        """base/parameter_control.py:85-96 flips ``requires_grad`` of parameter groups of the visual encoder; the first
-        group (indices 4..9) is exactly ``output_layer``.  The later groups reach into the body, whose backward
-        (IR-50 dgrad / wgrad) is not built: fail loudly rather than silently train nothing."""
+    def _release_plan(self):
+        """base/parameter_control.py:85-96 flips ``requires_grad`` of parameter groups of the visual encoder: group 1
+        (indices 4..9) is exactly ``output_layer``; groups 2 and 3 are stage 4 and the second half of stage 3, i.e. always
+        a SUFFIX of the body.  Returns None (nothing released / no autograd) or the index of the first released body
+        unit (len(body) when only the head is released).  Anything else fails loudly."""
         if not torch.is_grad_enabled():
-            return False
+            return None
         head = [p.requires_grad for p in self.output_layer.parameters()]
-        rest = [p.requires_grad for m in (self.input_layer, self.body) for p in m.parameters()]
-        if any(rest):
-            raise NotImplementedError("gradual release beyond the output layer needs the IR-50 body backward, which is not "
-                                      "built (SURVEY 8f rank 2): only base/parameter_control.py's first group is supported")
-        if any(head) and not all(head):
-            raise NotImplementedError("release the whole output layer (parameters 4..9) or nothing")
-        return all(head)
+        if any(p.requires_grad for p in self.input_layer.parameters()):
+            raise NotImplementedError("releasing the stem is not supported: the released units must be a suffix of the body")
+        flags = []
+        for u in self.body:
+            f = [p.requires_grad for p in u.parameters()]
+            if any(f) and not all(f):
+                raise NotImplementedError("release whole units (all parameters of a bottleneck_IR unit) or nothing")
+            flags.append(all(f))
+        if not any(head) and not any(flags):
+            return None
+        if not all(head):
+            raise NotImplementedError("release the whole output layer (parameters 4..9) first, as the reference does")
+        first = len(flags)
+        while first > 0 and flags[first - 1]:
+            first -= 1
+        if any(flags[:first]):
+            raise NotImplementedError("released body units must form a suffix of the body (the reference releases from the top)")
+        if first == 0:
+            raise NotImplementedError("the first unit stays frozen (the reference never releases below half of stage 3)")
+        return first
+
+    @staticmethod
+    def _released_unit(u, y):
+        pr = u.res_layer
+        sc = u.shortcut_layer if u.cin != u.depth else None
+        return _ReleasedUnit.apply(y, u, pr[0].weight, pr[0].bias, pr[1].weight, pr[2].weight, pr[3].weight, pr[4].weight,
+                                   pr[4].bias, sc[0].weight if sc is not None else None,
+                                   sc[1].weight if sc is not None else None, sc[1].bias if sc is not None else None)
 
     def _released_head(self, y, head_mask):
         bn2, fc, bn1 = self.output_layer[0], self.output_layer[3], self.output_layer[4]
@@ -388,7 +498,12 @@ class IR50(nn.Module):
         s, t = self._finalize(st, y0.numel() // 64, self.input_layer[1])
         y, xst = ops.bn_apply_nhwc(y0, s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True)
         del y0
-        for u, d in zip(self.body, P["units"]):
+        plan = self._release_plan()
+        first_released = len(P["units"]) if plan is None else plan
+        for i, (u, d) in enumerate(zip(self.body, P["units"])):
+            if i >= first_released:
+                y = self._released_unit(u, y)
+                continue
             s1, t1 = self._finalize(xst, y.numel() // u.cin, u.res_layer[0])
             tt = ops.conv2d(y, d["w1"], 3, 3, pad=(1, 1), in_scale=s1, in_shift=t1,
                             alpha=u.res_layer[2].weight.detach(), act1=ops.ACT_PRELU)
@@ -406,12 +521,14 @@ class IR50(nn.Module):
         nn_, h, w, c = y.shape
         if h != self.head_hw or w != self.head_hw:
             raise RuntimeError(f"IR50 head was built for {self.head_hw}x{self.head_hw} feature maps but got {h}x{w}")
-        s0, t0 = self._finalize(xst, y.numel() // c, self.output_layer[0])
         p_drop = self.output_layer[1].p
         if head_mask is None and p_drop > 0:
             self._dropout_calls += 1
             head_mask = ops.dropout_mask(tuple(y.shape), p_drop, 0x1f50 + self.dropout_seed, self._dropout_calls * y.numel(),
                                          y.device)
+        if plan is not None:
+            return self._released_head(y, head_mask)
+        s0, t0 = self._finalize(xst, y.numel() // c, self.output_layer[0])
         hfeat = ops.bn_apply_nhwc(y, s0, t0, mask=head_mask)
         k = h * w * c
         fc, bn1 = self.output_layer[3], self.output_layer[4]
@@ -435,6 +552,9 @@ class IR50(nn.Module):
             if self.precision == "bf16x3":
                 return self._forward_batch_stats_b3(x, head_mask)
             return self._forward_batch_stats(x, head_mask)
+        if self._release_plan() is not None:
+            raise NotImplementedError("released encoder parameters need model.train() with bn_mode = 'reference' (what the "
+                                      "reference's gradual release runs in); use torch.no_grad() for evaluation")
         if self.precision == "bf16x3":
             return self._forward_b3(x)
         P = self.pack()

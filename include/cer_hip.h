@@ -181,6 +181,18 @@ int cer_weight_norm_bwd(const float *dw, const float *v, const float *g, const f
 int cer_conv1d_wgrad(const float *dz, int dz_ld, const float *x, int x_ld, float *dw,
                      int R, int L, int Cout, int Cin, int k, int dil, void *stream);
 
+/* 2-D weight gradient (encoder units released for training, reference base/parameter_control.py:55-103):
+ * dW[co][ci][kh][kw] = sum over output pixels (n,ho,wo) of dZ[n,ho,wo,co] * X[n, ho*stride-pad_t+kh, wo*stride-pad_l+kw, ci]
+ * (zero outside the image).  dz dense [N*Ho*Wo, Cout], x dense NHWC, dw in torch's OIHW layout. */
+int cer_conv2d_wgrad(const float *dz, const float *x, float *dw, int N, int H, int W, int Ho, int Wo, int Cout, int Cin,
+                     int KH, int KW, int stride, int pad_t, int pad_l, void *stream);
+
+/* Channels-last PReLU with per-channel slopes (arcface_model.py:54).  Backward: dx = x > 0 ? dy : alpha*dy, and
+ * dalpha_terms = x > 0 ? 0 : x*dy, whose column sum (cer_col_sum) is the slope gradient. */
+int cer_prelu_fwd(const float *x, const float *alpha, float *y, size_t rows, int C, void *stream);
+int cer_prelu_bwd(const float *dy, const float *x, const float *alpha, float *dx, float *dalpha_terms, size_t rows, int C,
+                  void *stream);
+
 /* out[c] = sum_r a[r][c] * (b ? (b[r][c]-mean[c])*invstd[c] : 1); deterministic tree.
  * Bias gradients and the BatchNorm / LayerNorm parameter gradients. */
 size_t cer_col_sum_workspace_bytes(int R, int C);

@@ -146,3 +146,13 @@ def test_bad_arguments_raise():
         ops.conv2d(x, w, 3, 3, pad=(1, 1), act1=ops.ACT_PRELU)  # PReLU without alpha
     with pytest.raises(ValueError):
         ops.conv2d(x.cpu(), w, 3, 3)
+
+
+def test_output_grid_that_outruns_the_input_is_rejected():
+    """The staged kernels address rows by unsigned distances from the tile's first row; a forced out_hw beyond the natural
+    output size would make them wrap (found as a GPU fault while building the conv data gradient): loud error instead."""
+    from feature_vs_text_compound_emotion_amd import ops
+    x = torch.randn(2, 5, 5, 64).cuda()
+    w = ops.pack_conv_weight(torch.randn(64, 64, 3, 3).cuda())
+    with pytest.raises(RuntimeError, match="outruns"):
+        ops.conv2d(x, w, 3, 3, pad=(1, 1), out_hw=(6, 6))

@@ -20,7 +20,7 @@ from models.backbone import VisualBackbone  # noqa: E402  (reference)
 OUT = os.path.join(ROOT, "tests", "golden")
 
 
-def main():
+def run(groups, fname):
     torch.set_num_threads(8)
     n, hw, wseed, dseed = 6, 40, 21, 77
     vsd = synth.make_state_dict(synth.visual_backbone_spec("", hw // 8), seed=wseed)
@@ -32,10 +32,14 @@ def main():
     params = list(vb.parameters())
     for p in params:
         p.requires_grad = False
-    released = params[4:10]  # the reference's first visual group: np.arange(4, 10)
-    names = [k for k, _ in vb.named_parameters()][4:10]
-    assert names == ["backbone.output_layer.0.weight", "backbone.output_layer.0.bias", "backbone.output_layer.3.weight",
-                     "backbone.output_layer.3.bias", "backbone.output_layer.4.weight", "backbone.output_layer.4.bias"], names
+    idx = [i for a, b in groups for i in range(a, b)]  # ResnetParamControl.init_param_group: np.arange(*group)
+    released = [params[i] for i in idx]
+    all_names = [k for k, _ in vb.named_parameters()]
+    names = [all_names[i] for i in idx]
+    assert names[:6] == ["backbone.output_layer.0.weight", "backbone.output_layer.0.bias", "backbone.output_layer.3.weight",
+                         "backbone.output_layer.3.bias", "backbone.output_layer.4.weight", "backbone.output_layer.4.bias"], names
+    if len(groups) > 1:
+        assert names[6].startswith("backbone.body.21.") and names[-1] == "backbone.body.23.res_layer.4.bias", (names[6], names[-1])
     for p in released:
         p.requires_grad = True
     vb.train()
@@ -54,16 +58,24 @@ def main():
     out = {"meta": np.array([n, hw, wseed, dseed]), "emb": emb.detach().numpy(), "keep": keep}
     for name, p in zip(names, released):
         gr = p.grad.numpy()
-        key = name.replace("backbone.output_layer.", "g")
+        if name.startswith("backbone.output_layer."):
+            key = name.replace("backbone.output_layer.", "g")
+            out[key] = gr if gr.size < 20000 else gr[:8].copy()  # the FC weight gradient: first 8 rows + its norm
+        else:
+            key = "grad:" + name[len("backbone."):]
+            out[key] = gr if gr.size < 20000 else gr.reshape(-1)[:4096].copy()  # conv weights: first 4096 values + norm
         out[key + "_norm"] = np.array([np.linalg.norm(gr.astype(np.float64))])
-        out[key] = gr if gr.size < 20000 else gr[:8].copy()  # the FC weight gradient: first 8 rows + its norm
-    for k in ("backbone.output_layer.0.running_mean", "backbone.output_layer.0.running_var",
-              "backbone.output_layer.4.running_mean", "backbone.output_layer.4.running_var"):
-        out["after_" + k.replace("backbone.output_layer.", "")] = sd_after[k].numpy()
-    np.savez_compressed(os.path.join(OUT, "head_release_step.npz"), **out)
-    print({k: (v.shape if hasattr(v, "shape") else v) for k, v in out.items()})
-    print("size", os.path.getsize(os.path.join(OUT, "head_release_step.npz")))
+    stats = ["backbone.output_layer.0.running_mean", "backbone.output_layer.0.running_var",
+             "backbone.output_layer.4.running_mean", "backbone.output_layer.4.running_var"]
+    if len(groups) > 1:
+        stats += ["backbone.body.21.res_layer.0.running_var", "backbone.body.21.shortcut_layer.1.running_mean",
+                  "backbone.body.23.res_layer.4.running_var"]
+    for k in stats:
+        out["after_" + k.replace("backbone.output_layer.", "").replace("backbone.", "")] = sd_after[k].numpy()
+    np.savez_compressed(os.path.join(OUT, fname), **out)
+    print(fname, len(out), "arrays, size", os.path.getsize(os.path.join(OUT, fname)))
 
 
 if __name__ == "__main__":
-    main()
+    run([(4, 10)], "head_release_step.npz")               # module_dict["visual"][0]
+    run([(4, 10), (163, 187)], "body_release_step.npz")   # + module_dict["visual"][1]: stage 4 of the IR-50
