@@ -113,3 +113,34 @@ def test_train_step_on_cpu_stub_model():
     l0 = tr.train_step(X).item()
     l1 = tr.train_step(X).item()
     assert l1 < l0
+
+
+def test_gradual_release_groups_are_head_then_stage4_then_half_of_stage3():
+    """base/parameter_control.py:55-96: index groups into list(model['visual'].parameters())."""
+    from feature_vs_text_compound_emotion_amd.parameter_control import ResnetParamControl
+    from feature_vs_text_compound_emotion_amd.visual_backbone import VisualBackbone
+
+    class _T:
+        early_stopping, calls = 7, 0
+
+        def init_optimizer_and_scheduler(self, epoch=0):
+            self.calls += 1
+
+    vb = VisualBackbone(use_pretrained=False)
+    for p in vb.parameters():
+        p.requires_grad = False
+    names = [k for k, _ in vb.named_parameters()]
+    t = _T()
+    pc = ResnetParamControl(t, release_count=3)
+    spatial = {"visual": vb}
+    r1 = pc.release_param(spatial)
+    assert [n for n, p in vb.named_parameters() if p.requires_grad] == names[4:10]
+    assert all(n.startswith("backbone.output_layer.") for n in names[4:10]) and len(r1) == 6
+    assert vb.backbone._release_plan() == 24  # head only
+    pc.release_param(spatial)
+    assert names[163].startswith("backbone.body.21.") and vb.backbone._release_plan() == 21
+    pc.release_param(spatial)
+    assert names[142] == "backbone.body.18.res_layer.0.weight" and vb.backbone._release_plan() == 18
+    assert t.calls == 3 and t.early_stopping_counter == 7 and pc.release_count == 0
+    pc.release_param(spatial)
+    assert pc.early_stop
