@@ -178,6 +178,9 @@ def main():
     ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="IR-50 conv kernels: bf16x3 = split hi/lo bf16 operands, 3 bf16 MFMAs per product, fp32-class "
                          "accuracy (logit error ~1e-6); fp32 = exact fp32 MFMA")
+    ap.add_argument("--release", type=int, default=0, choices=[0, 1, 2, 3],
+                    help="gradual-release groups of the reference's ResnetParamControl to un-freeze before timing "
+                         "(0 = as the reference trains: encoder frozen; 1 = output layer; 2 = + stage 4; 3 = + half of stage 3)")
     ap.add_argument("--encoders", choices=["on", "off"], default="on",
                     help="on: VGGish (log-mel from 1 s PCM) and BERT (64 tokens) run on the GPU inside the step; "
                          "off: pre-computed per-frame features, as the reference trainer feeds them")
@@ -202,6 +205,11 @@ def main():
     model, _ = build_model(a.hw, a.length, dev)
     model.spatial["visual"].backbone.precision = a.precision
     model.train()
+    if a.release:
+        from feature_vs_text_compound_emotion_amd.parameter_control import ResnetParamControl
+        pc = ResnetParamControl(trainer=None, release_count=a.release)
+        for _ in range(a.release):
+            pc.release_param(model.spatial)
     ddp = ClipDataParallel(model, world_size=world)
     # the reference's torch.optim.SGD(momentum .9, nesterov, wd 1e-4, lr 1e-3 -- F8) as one fused launch over flat buffers
     opt = FlatNesterovSGD(ddp, lr=1e-3, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=True)
@@ -344,7 +352,8 @@ def main():
                                       "vggish/bert as pre-computed per-frame features (as the reference trainer feeds them)"),
                        "encoders_on_gpu": a.encoders == "on",
                        "clips_per_gpu": a.batch, "global_batch": a.batch * world, "frames_per_clip": a.length,
-                       "frame_hw": a.hw, "n_classes": 7, "conv_precision": a.precision, "parallelism": f"dp{world} over clips, flat-bucket RCCL all-reduce",
+                       "frame_hw": a.hw, "n_classes": 7, "released_encoder_groups": a.release,
+                       "trainable_parameters": int(sum(p.numel() for p in ddp.params)), "conv_precision": a.precision, "parallelism": f"dp{world} over clips, flat-bucket RCCL all-reduce",
                        "loss": float(loss.item())},
             "roofline": roofline,
         }

@@ -312,7 +312,10 @@ class _TailModel(nn.Module):
             x = X[m]
             if m == "video":
                 bsz, length = x.shape[0], x.shape[1]
-                with torch.no_grad():
+                # frozen encoder (the reference's default): no autograd graph.  After a gradual release
+                # (base/parameter_control.py) the released encoder parameters need the gradient of the embedding.
+                released = any(p.requires_grad for p in self.spatial["visual"].parameters())
+                with torch.set_grad_enabled(released and torch.is_grad_enabled()):
                     vis = self.spatial["visual"]
                     vis.backbone.dropout_seed = self.dropout_seed
                     rows = vis(x.reshape(-1, *x.shape[2:]))
