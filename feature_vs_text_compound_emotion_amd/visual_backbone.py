@@ -283,8 +283,10 @@ class IR50(nn.Module):
 
     # ------------------------------------------------------------------ bf16x3 packing
     def pack_b3(self):
-        """Eval-mode layouts for the bf16x3 kernels: weights as split (hi/lo bf16) planes with the post-conv
-        BatchNorms folded; every pre-conv BatchNorm becomes the PRODUCER's second output (next_affine)."""
+        """Eval-mode layouts for the bf16x3 kernels: weights as split (hi/lo bf16) planes with EVERY BatchNorm folded in:
+        post-conv BatchNorms as output scale + bias, pre-conv BatchNorms through ``ops.fold_input_bn_3x3`` (input scale
+        into the weights, input shift into the border-dependent ``bias9``), the head's BatchNorm2d/BatchNorm1d into the FC.
+        Each unit then writes ONE split tensor (its raw output, which is both the next conv's input and the shortcut)."""
         key = self._state_key()
         if self._packed_b3 is not None and key == self._packed_b3_key:
             return self._packed_b3
@@ -297,8 +299,9 @@ class IR50(nn.Module):
         units = []
         for u in self.body:
             d = {"stride": u.stride, "proj": u.cin != u.depth}
-            d["in_s"], d["in_b"] = self._bn_affine(u.res_layer[0])
-            d["w1"] = ops.split_bf16(ops.pack_conv_weight(u.res_layer[1].weight.detach().contiguous()))
+            in_s, in_b = self._bn_affine(u.res_layer[0])
+            w1, d["b9"] = ops.fold_input_bn_3x3(u.res_layer[1].weight.detach(), in_s, in_b)
+            d["w1"] = ops.split_bf16(w1)
             d["a1"] = u.res_layer[2].weight.detach().contiguous()
             s2, b2 = self._bn_affine(u.res_layer[4])
             d["w2"] = ops.split_bf16(ops.pack_conv_weight(u.res_layer[3].weight.detach().contiguous(), s2))
@@ -310,12 +313,14 @@ class IR50(nn.Module):
             units.append(d)
         P["units"] = units
         hw = self.head_hw
-        P["head_in"] = self._bn_affine(self.output_layer[0])
-        s4, t4 = self._bn_affine(self.output_layer[4])
+        s0, t0 = self._bn_affine(self.output_layer[0])       # BatchNorm2d(512) in front of the flatten
+        s4, t4 = self._bn_affine(self.output_layer[4])       # BatchNorm1d(512) behind the FC
         fc = self.output_layer[3]
-        w = fc.weight.detach().view(fc.out_features, -1, hw * hw).permute(0, 2, 1).contiguous().view(fc.out_features, -1)
+        w = fc.weight.detach().view(fc.out_features, -1, hw * hw).permute(0, 2, 1)  # [o][(h,w)][c]: K order (c,h,w) -> (h,w,c)
+        bias = fc.bias.detach() + (w * t0.view(1, 1, -1)).sum((1, 2))                 # W . t0
+        w = (w * s0.view(1, 1, -1)).contiguous().view(fc.out_features, -1)            # W . diag(s0)
         P["head_w"] = ops.split_bf16((w * s4.view(-1, 1)).contiguous())
-        P["head_b"] = (fc.bias.detach() * s4 + t4).contiguous()
+        P["head_b"] = (bias * s4 + t4).contiguous()
         self._packed_b3, self._packed_b3_key = P, key
         return P
 
@@ -342,29 +347,22 @@ class IR50(nn.Module):
         """Eval / frozen forward on the bf16x3 kernels (Cin = 3 stem on the fp32 small-Cin kernel)."""
         P = self.pack_b3()
         U = P["units"]
-        r = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), bias=P["stem_b"], alpha=P["stem_a"],
-                       act1=ops.ACT_PRELU, x_nchw=True, want_f32=False, out_split=True,
-                       next_affine=(U[0]["in_s"], U[0]["in_b"]))
-        x_raw, x_bn = r["split"], r["next"]
-        for i, d in enumerate(U):
+        xs = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), bias=P["stem_b"], alpha=P["stem_a"],
+                        act1=ops.ACT_PRELU, x_nchw=True, want_f32=False, out_split=True)["split"]
+        for d in U:
             s = d["stride"]
-            t = ops.conv2d_b3(x_bn, d["w1"], 3, 3, pad=(1, 1), alpha=d["a1"], act1=ops.ACT_PRELU)["split"]
-            last = i + 1 == len(U)
-            nxt = P["head_in"] if last else (U[i + 1]["in_s"], U[i + 1]["in_b"])
+            t = ops.conv2d_b3(xs, d["w1"], 3, 3, pad=(1, 1), bias9=d["b9"], alpha=d["a1"], act1=ops.ACT_PRELU)["split"]
             if d["proj"]:
-                sc = ops.conv2d_b3(x_raw, d["ws"], 1, 1, stride=s, bias=d["bs"])["split"]
-                r = ops.conv2d_b3(t, d["w2"], 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=sc, res_stride=1,
-                                  out_split=not last, next_affine=nxt)
+                sc = ops.conv2d_b3(xs, d["ws"], 1, 1, stride=s, bias=d["bs"])["split"]
+                xs = ops.conv2d_b3(t, d["w2"], 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=sc, res_stride=1)["split"]
             else:
-                r = ops.conv2d_b3(t, d["w2"], 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=x_raw, res_stride=s,
-                                  out_split=not last, next_affine=nxt)
-            x_raw, x_bn = r.get("split"), r["next"]
-        n, h, w, c = x_bn.shape
+                xs = ops.conv2d_b3(t, d["w2"], 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=xs, res_stride=s)["split"]
+        n, h, w, c = xs.shape
         if h != self.head_hw or w != self.head_hw:
             raise RuntimeError(f"IR50 head was built for {self.head_hw}x{self.head_hw} feature maps "
                                f"({8 * self.head_hw}x{8 * self.head_hw} frames) but got {h}x{w}")
         k = h * w * c
-        e = ops.conv2d_b3(x_bn.view(n, 1, 1, k), P["head_w"], 1, 1, bias=P["head_b"], split_k=self._head_split_k(n, k),
+        e = ops.conv2d_b3(xs.view(n, 1, 1, k), P["head_w"], 1, 1, bias=P["head_b"], split_k=self._head_split_k(n, k),
                           out_f32=True, out_split=False)["y"]
         return ops.l2norm_rows(e.view(n, -1))
 
