@@ -4,6 +4,7 @@ Everything here is a thin marshalling layer: shape checks, output allocation,
 one C call.  No arithmetic happens in Python.
 """
 import ctypes
+import os
 
 import torch
 
@@ -249,6 +250,20 @@ def conv2d_b3(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bi
         e1.record()
         CONV_TRACE.append((lib.cer_conv2d_b3_tile(ctypes.byref(d)), 2.0 * n * ho * wo * cout * cin * kh * kw, e0, e1))
     return res
+
+
+AUTO_SPLIT_K = os.environ.get("CER_TAIL_SPLITK", "1") != "0"
+
+
+def auto_split_k(m, cout, kdim):
+    """Split-K factor for the small GEMMs of the trainable tail (M = B*L rows): a 1024 x 128 output is 32 tiles of 64 x 64
+    on a 256-CU chip, so the K loop is cut until ~256 blocks are in flight (deterministic slabs + one reduce launch)."""
+    if not AUTO_SPLIT_K:
+        return 1
+    tiles = ((m + 63) // 64) * ((cout + 63) // 64)
+    if tiles >= 128 or kdim < 256:
+        return 1
+    return max(1, min(kdim // 128, 256 // tiles, 16))
 
 
 def linear(x2d, w_packed, bias=None, act=ACT_NONE, split_k=1, residual=None, out=None):

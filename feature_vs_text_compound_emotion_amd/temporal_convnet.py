@@ -64,7 +64,7 @@ def _conv_rows(x_rows, w_oihw3, bsz, length, k, dil, **kw):
     cout, cin, _ = w_oihw3.shape
     wp = ops.pack_conv_weight(w_oihw3.view(cout, cin, k, 1))
     y = ops.conv2d(x_rows.view(bsz, length, 1, cin), wp, k, 1, dil=(dil, 1), pad=((k - 1) * dil, 0),
-                   out_hw=(length, 1), **kw)
+                   out_hw=(length, 1), split_k=ops.auto_split_k(bsz * length, cout, cin * k), **kw)
     return y.view(bsz * length, cout)
 
 
@@ -74,7 +74,7 @@ def _dgrad_rows(dz_rows, w_oihw3, bsz, length, k, dil, residual=None):
     wt = ops.pack_conv_weight(w_oihw3.view(cout, cin, k, 1), flip=True, transpose=True)
     res = residual.view(bsz, length, 1, cin) if residual is not None else None
     y = ops.conv2d(dz_rows.view(bsz, length, 1, cout), wt, k, 1, dil=(dil, 1), pad=(0, 0), out_hw=(length, 1),
-                   residual=res)
+                   residual=res, split_k=ops.auto_split_k(bsz * length, cin, cout * k))
     return y.view(bsz * length, cin)
 
 
