@@ -748,13 +748,18 @@ __device__ __forceinline__ int swz16(int q) { return (0x78 >> (2 * q)) & 3; }  /
 // free is slot = chunk ^ F[(row >> 2) & 3] with F = {0, 2, 3, 1} (applied on the DMA's source side as before).
 // NW = 4 waves (two blocks per CU) or 8 waves: the 256x256 tile of 8 waves x (128 pixels x 64 couts) halves the
 // L2 -> LDS bytes per FLOP of the 128x128 tile and the LDS fragment reads per MFMA drop by a quarter; one block per CU.
-template <int BM, int BN, int WP, int WC, int NW = 4>
+// STAGES = 2: the DMA of step s+1 flies during step s (vmcnt(0) at every step).  STAGES = 3: two steps ahead with a
+// counted vmcnt -- the 128x64 tile's step is only 384 MFMA cycles per wave, less than an L2 round trip under load (PMC:
+// 42 % of its wave cycles parked at the wait/barrier), so it wants the deeper ring even at 2 instead of 3 blocks per CU.
+template <int BM, int BN, int WP, int WC, int NW = 4, int STAGES = 2>
 __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_b3_dma16_kernel(ConvArgs p) {
     static_assert(WP * WC == NW && BM % (16 * NW) == 0 && BN % (16 * NW) == 0, "1-KiB pieces are dealt round-robin to the waves");
     constexpr int BKT = 32, ROWB = BKT * 2;        // bytes per row and plane
     constexpr int XP = BM / (16 * NW), WQ = BN / (16 * NW);  // 1-KiB pieces per wave and plane
     constexpr int PX = BM * ROWB, PW = BN * ROWB;  // plane sizes in bytes
     constexpr int BUF = 2 * PX + 2 * PW;
+    constexpr int NDMA = 2 * XP + 2 * WQ;  // DMA instructions a wave issues per step
+    static_assert(STAGES == 2 || STAGES == 3, "ring depth");
     constexpr int TP = BM / (16 * WP), TC = BN / (16 * WC);  // 16x16 tiles per wave
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_b3[];
@@ -856,19 +861,25 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_b3_dma16_kernel
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
 
-    if (s_begin < s_end) issue(s_begin, 0);
+#pragma unroll
+    for (int st = 0; st < STAGES - 1; ++st)
+        if (s_begin + st < s_end) issue(s_begin + st, st);
 
     // fragment addresses: row * 64 bytes + swizzled slot of k-chunk kg
     const int sw = swz16((l15 >> 2) & 3);
     const int arow = (wc * TC * 16 + l15) * ROWB + ((kg ^ sw) << 4);  // A = weights: row = cout
     const int brow = (wp * TP * 16 + l15) * ROWB + ((kg ^ sw) << 4);  // B = activations: row = pixel
-    for (int s = s_begin; s < s_end; ++s) {
-        const int cur = (s - s_begin) & 1;
-        // every wave has seen its own pieces of step s land, and (barrier) everyone else's; the barrier also
-        // closes the reads of step s-1, whose buffer the next DMA overwrites
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    int cur = 0;
+    for (int s = s_begin; s < s_end; ++s, cur = (cur + 1 == STAGES ? 0 : cur + 1)) {
+        // every wave has seen its own pieces of step s land (the STAGES-2 younger steps may still fly), and (barrier)
+        // everyone else's; the barrier also closes the reads of step s-1, whose buffer the next DMA overwrites
+        if (STAGES == 3 && s + 1 < s_end) {
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
-        if (s + 1 < s_end) issue(s + 1, cur ^ 1);
+        if (s + STAGES - 1 < s_end) issue(s + STAGES - 1, cur == 0 ? STAGES - 1 : cur - 1);
         const unsigned char *Xh = smem + cur * BUF, *Xl = Xh + PX, *Wh = Xh + 2 * PX, *Wl = Wh + PW;
         bf16x8 ah[TC], al[TC], bh[TP], bl[TP];
 #pragma unroll
@@ -1258,12 +1269,12 @@ static int launch_b3_dma(const ConvArgs &a, hipStream_t st) {
     return CER_OK;
 }
 
-template <int BM, int BN, int WP, int WC, int NW = 4>
+template <int BM, int BN, int WP, int WC, int NW = 4, int STAGES = 2>
 static int launch_b3_dma16(const ConvArgs &a, hipStream_t st) {
     if ((long long)BN * a.Kpad * 2 >= (1ll << 31))
         return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3, LDS-DMA): weight panel exceeds 31-bit offsets");
-    const size_t lds = (size_t)2 * (2 * BM + 2 * BN) * 64;
-    auto k = conv_b3_dma16_kernel<BM, BN, WP, WC, NW>;
+    const size_t lds = (size_t)STAGES * (2 * BM + 2 * BN) * 64;
+    auto k = conv_b3_dma16_kernel<BM, BN, WP, WC, NW, STAGES>;
     if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, a.split_k), dim3(NW * 64), lds, st, a);
     CER_HIP_CHECK(hipGetLastError());
@@ -1329,6 +1340,7 @@ int conv_b3_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, 
         case 42: bm = 128; bn = 64; bk = 32; break;
         case 44: bm = 64; bn = 128; bk = 32; break;
         case 45: bm = 64; bn = 64; bk = 32; break;
+        case 52: bm = 128; bn = 64; bk = 32; break;   // tile 42 with a 3-deep LDS ring (A/B variant: -2..-10 %, 2 blocks/CU)
         case 46: bm = 256; bn = 256; bk = 32; break;  // 8 waves (A/B variant: ties tile 41; 256x128x8 waves and 256x64x4 waves lost 3-18 %)
         case 31: bm = 256; bn = 128; bk = 32; break;
         case 32: bm = 256; bn = 64; bk = 32; break;
@@ -1362,6 +1374,7 @@ int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 42: return launch_b3_dma16<128, 64, 2, 2>(a, st);
         case 44: return launch_b3_dma16<64, 128, 1, 4>(a, st);
         case 45: return launch_b3_dma16<64, 64, 2, 2>(a, st);
+        case 52: return launch_b3_dma16<128, 64, 2, 2, 4, 3>(a, st);
         case 46: return launch_b3_dma16<256, 256, 2, 4, 8>(a, st);
         case 31: return launch_b3_win<256, 128, 4, 2>(a, st);
         case 32: return launch_b3_win<256, 64, 8, 1>(a, st);

@@ -34,6 +34,8 @@ def test_split_is_round_to_nearest_and_exact_to_16_bits():
     (2, 128, 256, 10, 3, 1, 41), (5, 64, 128, 9, 3, 2, 41), (3, 96, 100, 7, 3, 1, 41), (4, 64, 128, 9, 1, 2, 41),
     (3, 64, 64, 12, 3, 1, 42), (3, 64, 96, 7, 3, 1, 42), (2, 256, 256, 10, 3, 1, 44), (2, 128, 256, 10, 3, 2, 44),
     (3, 64, 96, 7, 3, 1, 45), (1, 32, 40, 5, 3, 1, 45), (7, 512, 512, 5, 3, 1, 41),
+    # 3-deep LDS ring (counted vmcnt)
+    (3, 64, 64, 12, 3, 1, 52), (3, 64, 96, 7, 3, 1, 52), (2, 128, 256, 10, 3, 2, 52), (4, 64, 128, 9, 1, 2, 52),
     # 8-wave 256x256 tile
     (4, 128, 256, 10, 3, 1, 46), (7, 256, 512, 5, 3, 2, 46), (3, 96, 300, 7, 3, 1, 46), (4, 64, 256, 9, 3, 2, 46)])
 def test_conv_b3_matches_fp32(n, cin, cout, hw, k, stride, tile):
@@ -82,7 +84,7 @@ def test_conv_b3_window_kernel_rejects_what_it_cannot_take():
         ops.conv2d_b3(xs, ws, 3, 3, stride=2, pad=(1, 1), tile=31)
 
 
-@pytest.mark.parametrize("tile", [0, 6, 11, 12, 41, 42, 44, 46])
+@pytest.mark.parametrize("tile", [0, 6, 11, 12, 41, 42, 44, 46, 52])
 def test_conv_b3_fused_epilogue_outputs(tile):
     from feature_vs_text_compound_emotion_amd import ops
     g = torch.Generator().manual_seed(5)
@@ -115,7 +117,7 @@ def test_linear_b3_split_k():
     ref = F.linear(x, w, b)
     xs = ops.split_bf16(x.cuda().view(m, 1, 1, k))
     ws = ops.split_bf16(w.cuda().contiguous())
-    for tile in (0, 6, 11, 15, 41, 45, 46):
+    for tile in (0, 6, 11, 15, 41, 45, 46, 52):
         r = ops.conv2d_b3(xs, ws, 1, 1, bias=b.cuda(), split_k=5, out_f32=True, out_split=False, tile=tile)
         assert (r["y"].view(m, cout).cpu() - ref).abs().max().item() < 5e-5
 
