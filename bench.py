@@ -27,9 +27,9 @@ FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 25
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak; the bf16x3 kernels spend 3 MFMAs per product -> 833.3 effective
 MODS = ["video", "vggish", "bert"]
 # kernel variant ids reported by cer_conv2d_b3_tile -> names as rocprofv3 prints them (csrc/conv_b3.hip)
-B3_KERNEL_NAMES = {41: "cer::conv_b3_dma16_kernel<128, 128, 2, 2, 4>", 42: "cer::conv_b3_dma16_kernel<128, 64, 2, 2, 4>",
-                   44: "cer::conv_b3_dma16_kernel<64, 128, 1, 4, 4>", 45: "cer::conv_b3_dma16_kernel<64, 64, 2, 2, 4>",
-                   46: "cer::conv_b3_dma16_kernel<256, 256, 2, 4, 8>"}
+B3_KERNEL_NAMES = {41: "cer::conv_b3_dma16_kernel<128, 128, 2, 2, 4, 2>", 42: "cer::conv_b3_dma16_kernel<128, 64, 2, 2, 4, 2>",
+                   44: "cer::conv_b3_dma16_kernel<64, 128, 1, 4, 4, 2>", 45: "cer::conv_b3_dma16_kernel<64, 64, 2, 2, 4, 2>",
+                   46: "cer::conv_b3_dma16_kernel<256, 256, 2, 4, 8, 2>"}
 
 
 def ir50_forward_flops(hw):
@@ -59,7 +59,7 @@ def build_model(hw, length, device):
     return model.to(device), sd
 
 
-def measured_traffic(hw, batch, length, encoders, precision):
+def measured_traffic(hw, batch, length, encoders, precision, kernel=None):
     """HBM bytes per step of cer::conv_igemm_kernel from the committed rocprofv3 PMC passes
     (tools/collect_traffic.py: FETCH_SIZE x2 + WRITE_SIZE, separate passes, gfx950 corrections).  PMC
     counters cannot be read from inside the timed process, so the value is looked up by configuration
@@ -71,6 +71,8 @@ def measured_traffic(hw, batch, length, encoders, precision):
         return None
     if (str(t.get("batch")), str(t.get("length")), t.get("encoders")) != (str(batch), str(length), encoders):
         return None
+    if kernel is not None:  # per launch of one kernel variant, like roofline.achieved
+        return t.get("per_kernel", {}).get(kernel, {}).get("hbm_bytes_per_launch")
     return t["hbm_bytes_per_step"]
 
 
@@ -277,10 +279,12 @@ def main():
 
     # per kernel variant: algorithmic FLOPs of its launches / their HIP-event durations (launch stream), over the timed steps
     kernels = {}
-    for tile, fl, e0, e1 in (trace or []):
-        k = kernels.setdefault(B3_KERNEL_NAMES.get(tile, f"conv_b3 tile {tile}"), {"launches": 0, "flops": 0.0, "ms": 0.0})
+    for tile, fl, e0, e1, nbytes in (trace or []):
+        k = kernels.setdefault(B3_KERNEL_NAMES.get(tile, f"conv_b3 tile {tile}"),
+                               {"launches": 0, "flops": 0.0, "ms": 0.0, "algo_bytes": 0.0})
         k["launches"] += 1
         k["flops"] += fl
+        k["algo_bytes"] += nbytes
         k["ms"] += e0.elapsed_time(e1)
     for k in kernels.values():
         k["launches_per_step"] = k["launches"] / a.steps
@@ -289,6 +293,7 @@ def main():
         k["achieved_tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12
         k["frac"] = k["achieved_tflops"] / peak
         k["ms_per_step"] = k.pop("ms") / a.steps
+        k["algorithmic_bytes_per_launch"] = k["algo_bytes"] / k["launches"]
         del k["flops"]
     dominant = max(kernels, key=lambda n: kernels[n]["ms_per_step"]) if kernels else None
 
@@ -327,7 +332,12 @@ def main():
                     "algorithmic_flops_per_launch": kd["flops_per_launch"],
                     "definition": "algorithmic FLOPs (2*M*Cout*Cin*KH*KW) of this kernel's launches / their summed HIP-event "
                                   "durations on the launch stream over the timed steps",
-                    "traffic": measured_traffic(a.hw, a.batch, a.length, a.encoders, a.precision), "traffic_note": traffic_note,
+                    "traffic": measured_traffic(a.hw, a.batch, a.length, a.encoders, a.precision, dominant),
+                    "traffic_note": "HBM bytes per launch of this kernel (rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes, "
+                                    "FETCH x2 per the gfx950 correction, profiles/round1b_traffic_*.json); algorithmic bytes per "
+                                    "launch = split input + output tensors + weights",
+                    "algorithmic_bytes_per_launch": kd["algo_bytes"] / kd["launches"],
+                    "traffic_per_step_all_convs": measured_traffic(a.hw, a.batch, a.length, a.encoders, a.precision),
                     "all_kernels": kernels, "encoder_span": span}
     else:
         roofline = {"bound": "mfma", "kernel": "cer::conv_igemm_kernel (IR-50 forward: 52 implicit-GEMM convs + head FC, "

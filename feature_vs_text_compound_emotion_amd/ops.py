@@ -172,7 +172,7 @@ def _dev_bf16(t, name):
 
 
 # bench.py sets this to a list to time every bf16x3 conv launch with HIP events on the launch stream:
-# (kernel variant id, algorithmic FLOPs, start event, end event)
+# (kernel variant id, algorithmic FLOPs, start event, end event, algorithmic bytes)
 CONV_TRACE = None
 
 
@@ -248,7 +248,11 @@ def conv2d_b3(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bi
     check(lib.cer_conv2d_run(ctypes.byref(d), ctypes.byref(io), ptr(ws), ws_bytes, current_stream()), "cer_conv2d_run")
     if CONV_TRACE is not None:
         e1.record()
-        CONV_TRACE.append((lib.cer_conv2d_b3_tile(ctypes.byref(d)), 2.0 * n * ho * wo * cout * cin * kh * kw, e0, e1))
+        # algorithmic bytes: split input (4 B/elt) + every output tensor written + split weights + residual read
+        nout = n * ho * wo * cout
+        nbytes = 4.0 * n * h * wd * cin + 4.0 * nout * (int(out_f32) + int(out_split) + int(next_affine is not None)) + \
+            4.0 * cout * cin * kh * kw + (4.0 * nout if residual is not None else 0.0)
+        CONV_TRACE.append((lib.cer_conv2d_b3_tile(ctypes.byref(d)), 2.0 * n * ho * wo * cout * cin * kh * kw, e0, e1, nbytes))
     return res
 
 

@@ -12,6 +12,9 @@ import json
 import sys
 
 
+PER_KERNEL = {}
+
+
 def total(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     s, n = 0.0, 0
@@ -19,6 +22,9 @@ def total(d, counter):
         if ("conv_igemm_kernel" in r["Kernel_Name"] or "conv_b3" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
             s += float(r["Counter_Value"])
             n += 1
+            k = PER_KERNEL.setdefault(r["Kernel_Name"].split("(")[0].replace("void ", ""), {})
+            k[counter] = k.get(counter, 0.0) + float(r["Counter_Value"])
+            k[counter + "_launches"] = k.get(counter + "_launches", 0) + 1
     return s, n
 
 
@@ -32,7 +38,11 @@ def main():
            "fetch_bytes_per_step": 2.0 * f * 1024 / steps, "write_bytes_per_step": w * 1024 / steps,
            "hbm_bytes_per_step": (2.0 * f + w) * 1024 / steps,
            "raw": {"FETCH_SIZE_KiB_sum": f, "WRITE_SIZE_KiB_sum": w, "dispatches": [nf, nw]},
-           "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE x1, KiB -> bytes", **extra}
+           "correction": "FETCH_SIZE x2 (gfx950 counts 64 B per 128-B request), WRITE_SIZE x1, KiB -> bytes",
+           "per_kernel": {k: {"launches": v.get("FETCH_SIZE_launches", 0),
+                              "hbm_bytes_per_launch": (2.0 * v.get("FETCH_SIZE", 0.0) / max(v.get("FETCH_SIZE_launches", 1), 1) +
+                                                       v.get("WRITE_SIZE", 0.0) / max(v.get("WRITE_SIZE_launches", 1), 1)) * 1024}
+                          for k, v in PER_KERNEL.items()}, **extra}
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))
 

@@ -12,5 +12,5 @@ timeout -k 10 500 rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$OUT/fetch"
 timeout -k 10 500 rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$OUT/write" -o w -- python3 $ARGS > "$OUT/write.log" 2>&1
 python3 tools/collect_traffic.py "$OUT/fetch" "$OUT/write" 4 "$OUT/traffic.json" batch=32 length=32 encoders=on hw=$HW precision=bf16x3
 grep "^{\"metric" "$OUT/bench_under_rocprof.log" > "$OUT/bench_under_rocprof.json"
-rm -f "$OUT"/stats/*kernel_trace.csv "$OUT"/fetch/*.csv "$OUT"/write/*.csv   # large; the summaries stay
+rm -f "$OUT"/stats/*kernel_trace.csv "$OUT"/fetch/*.csv "$OUT"/write/*.csv   # large; the summaries (traffic.json incl. per-kernel per-launch bytes) stay
 ls "$OUT" "$OUT/stats"
