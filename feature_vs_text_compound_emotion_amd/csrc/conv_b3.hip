@@ -907,7 +907,100 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_b3_dma16_kernel
             }
     }
 
-    // ---- epilogue: D[i = cout][j = pixel] of a 16x16 tile: lane holds couts 4*(lane>>4) + 0..3 of pixel lane&15 ----
+    // ---- epilogue ----
+    // Accumulator layout: D[i = cout][j = pixel] of a 16x16 tile, lane = couts 4*(lane>>4) + 0..3 of pixel lane&15.  Storing
+    // straight from it means 16 scattered 16-byte pieces per instruction and one fully inlined copy of the (large) fused
+    // epilogue per 16x16 tile -- 20-40k instructions, several times the instruction cache, and as long as the whole K loop
+    // of a K = 576 layer.  So the tile goes through LDS once (the staging buffers are free now): rows of BN floats, 16-byte
+    // granules XOR-swizzled by (row & 15) so that the 16 pixels of a ds_write_b128 group hit 16 different granules; then
+    // ONE compact loop in which consecutive lanes own consecutive couts of a pixel (1 KiB contiguous per wave store).
+    constexpr bool LDSEPI = BM * BN * 4 <= STAGES * BUF;
+    if constexpr (LDSEPI) {
+        constexpr int G = BN / 4;               // 16-byte granules per row (>= 16)
+        constexpr int RPI = NW * 64 / G;        // rows per loop iteration
+        float *Ct = reinterpret_cast<float *>(smem_b3);
+        __syncthreads();  // every wave is done with the fragment reads of the last step
+        static_for<TP>([&](auto B) {
+            constexpr int b = decltype(B)::v;
+            const int ml = (wp * TP + b) * 16 + l15;
+            static_for<TC>([&](auto A) {
+                constexpr int a = decltype(A)::v;
+                const int g = (wc * TC + a) * 4 + kg;
+                *reinterpret_cast<f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2)) = acc[a][b];
+            });
+        });
+        __syncthreads();
+        const int g = tid % G, r0 = tid / G;
+        const int c = c0 + g * 4;
+        float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        // row / column of the thread's first pixel once (bias9), then stepped without divisions
+        int ho = 0, wo = 0;
+        if (p.bias9) {
+            const int mm = m0 + r0 < p.M ? m0 + r0 : 0;
+            const int r = mm % (p.Ho * p.Wo);
+            ho = r / p.Wo;
+            wo = r - ho * p.Wo;
+        }
+        for (int ml = r0; ml < BM; ml += RPI) {
+            const int m = m0 + ml;
+            if (m >= p.M) break;
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2));
+            float v[4] = {q[0], q[1], q[2], q[3]};
+            if (c < p.Cout) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1[e] += v[e];
+                    s2[e] += v[e] * v[e];
+                }
+                if (p.split_k > 1) {
+                    float *dst = p.y + ((size_t)split * p.M + m) * p.Cout + c;
+                    if (((p.Cout & 3) == 0) && c + 3 < p.Cout) {
+                        *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (c + e < p.Cout) dst[e] = v[e];
+                    }
+                } else {
+                    const float *brow = p.bias;
+                    if (p.bias9) {
+                        const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
+                        brow = p.bias9 + (size_t)(3 * ry + rx) * p.Cout;
+                    }
+                    epilogue_store4(p, m, c, v, brow);
+                }
+            }
+            if (p.bias9) {  // advance RPI pixels
+                wo += RPI;
+                while (wo >= p.Wo) {
+                    wo -= p.Wo;
+                    if (++ho == p.Ho) ho = 0;
+                }
+            }
+        }
+        if (p.stats) {
+            __syncthreads();  // Ct has been consumed
+            float *red = reinterpret_cast<float *>(smem_b3);  // [RPI][2][BN]
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                red[(r0 * 2 + 0) * BN + g * 4 + e] = s1[e];
+                red[(r0 * 2 + 1) * BN + g * 4 + e] = s2[e];
+            }
+            __syncthreads();
+            if (tid < BN && c0 + tid < p.Cout) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < RPI; ++w) {
+                    t1 += red[(w * 2 + 0) * BN + tid];
+                    t2 += red[(w * 2 + 1) * BN + tid];
+                }
+                p.stats[((size_t)tile_m * 2 + 0) * p.Cout + c0 + tid] = t1;
+                p.stats[((size_t)tile_m * 2 + 1) * p.Cout + c0 + tid] = t2;
+            }
+        }
+        return;
+    }
+    // ---- direct epilogue (tiles whose accumulators do not fit the staging LDS: the 8-wave 256x256 variant) ----
     static_for<TP>([&](auto B) {
         constexpr int b = decltype(B)::v;
         const int m = m0 + (wp * TP + b) * 16 + l15;
@@ -1321,11 +1414,12 @@ int conv_b3_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, 
     if (tile == 0) {
         // measured per layer shape on MI355X (tools/bench_conv.py): the LDS-DMA kernels beat their
         // register-staged twins everywhere and the 16x16x32 MFMA shape beats 32x32x16 by 8-18 % (higher sustained clock);
-        // 128x64 tiles win while K is short (Cin <= 128: more, shorter blocks hide the prologue / epilogue), 128x128
-        // once K >= 2304; small grids take 64-row tiles
+        // with the compact LDS epilogue the 128x128 tile wins for every Cout >= 128 (also at K = 576 / 1152), 128x64
+        // serves Cout <= 64, small grids take 64-row tiles
         const long long t128 = (M + 127) / 128 * ((Cout + 127) / 128);
+        (void)K;
         if (Cout <= 64) tile = 42;
-        else if (t128 >= 512) tile = K <= 1152 ? 42 : 41;
+        else if (t128 >= 512) tile = 41;
         else tile = Cout >= 128 ? 44 : 45;
     }
     switch (tile) {
