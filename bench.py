@@ -29,7 +29,7 @@ MODS = ["video", "vggish", "bert"]
 # kernel variant ids reported by cer_conv2d_b3_tile -> names as rocprofv3 prints them (csrc/conv_b3.hip)
 B3_KERNEL_NAMES = {41: "cer::conv_b3_dma16_kernel<128, 128, 2, 2, 4, 2>", 42: "cer::conv_b3_dma16_kernel<128, 64, 2, 2, 4, 2>",
                    44: "cer::conv_b3_dma16_kernel<64, 128, 1, 4, 4, 2>", 45: "cer::conv_b3_dma16_kernel<64, 64, 2, 2, 4, 2>",
-                   46: "cer::conv_b3_dma16_kernel<256, 256, 2, 4, 8, 2>"}
+                   46: "cer::conv_b3_dma16_kernel<256, 256, 2, 4, 8, 2>", 48: "cer::conv_b3_dma16_kernel<256, 64, 4, 1, 4, 2>"}
 
 
 def ir50_forward_flops(hw):

@@ -1415,10 +1415,10 @@ int conv_b3_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, 
         // measured per layer shape on MI355X (tools/bench_conv.py): the LDS-DMA kernels beat their
         // register-staged twins everywhere and the 16x16x32 MFMA shape beats 32x32x16 by 8-18 % (higher sustained clock);
         // with the compact LDS epilogue the 128x128 tile wins for every Cout >= 128 (also at K = 576 / 1152), 128x64
-        // serves Cout <= 64, small grids take 64-row tiles
+        // or (large M) 256x64 serve Cout <= 64, small grids take 64-row tiles
         const long long t128 = (M + 127) / 128 * ((Cout + 127) / 128);
         (void)K;
-        if (Cout <= 64) tile = 42;
+        if (Cout <= 64) tile = (M + 255) / 256 >= 512 ? 48 : 42;  // 256x64: 226 vs 204 TF/s on 64->64 @224x224
         else if (t128 >= 512) tile = 41;
         else tile = Cout >= 128 ? 44 : 45;
     }
@@ -1439,6 +1439,7 @@ int conv_b3_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, 
         case 42: bm = 128; bn = 64; bk = 32; break;
         case 44: bm = 64; bn = 128; bk = 32; break;
         case 45: bm = 64; bn = 64; bk = 32; break;
+        case 48: bm = 256; bn = 64; bk = 32; break;   // 4 waves x (64 pixels x 64 couts)
         case 52: bm = 128; bn = 64; bk = 32; break;   // tile 42 with a 3-deep LDS ring (A/B variant: -2..-10 %, 2 blocks/CU)
         case 46: bm = 256; bn = 256; bk = 32; break;  // 8 waves (A/B variant: ties tile 41; 256x128x8 waves and 256x64x4 waves lost 3-18 %)
         case 31: bm = 256; bn = 128; bk = 32; break;
@@ -1473,6 +1474,7 @@ int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 42: return launch_b3_dma16<128, 64, 2, 2>(a, st);
         case 44: return launch_b3_dma16<64, 128, 1, 4>(a, st);
         case 45: return launch_b3_dma16<64, 64, 2, 2>(a, st);
+        case 48: return launch_b3_dma16<256, 64, 4, 1>(a, st);
         case 52: return launch_b3_dma16<128, 64, 2, 2, 4, 3>(a, st);
         case 46: return launch_b3_dma16<256, 256, 2, 4, 8>(a, st);
         case 31: return launch_b3_win<256, 128, 4, 2>(a, st);

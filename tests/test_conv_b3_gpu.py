@@ -34,6 +34,8 @@ def test_split_is_round_to_nearest_and_exact_to_16_bits():
     (2, 128, 256, 10, 3, 1, 41), (5, 64, 128, 9, 3, 2, 41), (3, 96, 100, 7, 3, 1, 41), (4, 64, 128, 9, 1, 2, 41),
     (3, 64, 64, 12, 3, 1, 42), (3, 64, 96, 7, 3, 1, 42), (2, 256, 256, 10, 3, 1, 44), (2, 128, 256, 10, 3, 2, 44),
     (3, 64, 96, 7, 3, 1, 45), (1, 32, 40, 5, 3, 1, 45), (7, 512, 512, 5, 3, 1, 41),
+    # 256x64 tile (Cout <= 64 at large M)
+    (3, 64, 64, 12, 3, 1, 48), (3, 64, 40, 7, 3, 1, 48), (5, 128, 64, 9, 3, 2, 48), (4, 64, 64, 9, 1, 2, 48),
     # 3-deep LDS ring (counted vmcnt)
     (3, 64, 64, 12, 3, 1, 52), (3, 64, 96, 7, 3, 1, 52), (2, 128, 256, 10, 3, 2, 52), (4, 64, 128, 9, 1, 2, 52),
     # 8-wave 256x256 tile
@@ -84,7 +86,7 @@ def test_conv_b3_window_kernel_rejects_what_it_cannot_take():
         ops.conv2d_b3(xs, ws, 3, 3, stride=2, pad=(1, 1), tile=31)
 
 
-@pytest.mark.parametrize("tile", [0, 6, 11, 12, 41, 42, 44, 46, 52])
+@pytest.mark.parametrize("tile", [0, 6, 11, 12, 41, 42, 44, 46, 48, 52])
 def test_conv_b3_fused_epilogue_outputs(tile):
     from feature_vs_text_compound_emotion_amd import ops
     g = torch.Generator().manual_seed(5)
