@@ -12,6 +12,7 @@ _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libcer_hip.so")
 
 ACT_NONE, ACT_PRELU, ACT_LEAKY, ACT_RELU, ACT_GELU = 0, 1, 2, 3, 4
+STORE_NONE, STORE_BF16, STORE_F16 = 0, 1, 2
 
 
 class ConvDesc(Structure):
@@ -19,7 +20,7 @@ class ConvDesc(Structure):
         "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "dil_h", "dil_w", "pad_t", "pad_l",
         "x_nchw", "res_stride", "Hr", "Wr", "act1", "act2")] + [("slope", c_float), ("split_k", c_int32),
                                                                 ("tile", c_int32), ("x_ld", c_int32),
-                                                                ("y_ld", c_int32)]
+                                                                ("y_ld", c_int32), ("storage", c_int32)]
 
 
 _P = c_void_p
@@ -41,6 +42,9 @@ _SIGNATURES = {
     "cer_conv2d_stats_tiles": (c_int, [POINTER(ConvDesc), c_int]),
     "cer_conv2d_run": (c_int, [POINTER(ConvDesc), POINTER(ConvIO), _P, c_size_t, _P]),
     "cer_conv2d_b3_tile": (c_int, [POINTER(ConvDesc)]),
+    "cer_conv2d_n16_tile": (c_int, [POINTER(ConvDesc)]),
+    "cer_to_n16": (c_int, [_P, _P, _P, c_int, _P, c_size_t, c_int, _P]),
+    "cer_from_n16": (c_int, [_P, _P, c_size_t, c_int, _P]),
     "cer_split_bf16": (c_int, [_P, _P, _P, c_int, _P, _P, c_size_t, _P]),
     "cer_conv2d_fwd": (c_int, [POINTER(ConvDesc), _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "cer_bn_finalize_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -50,6 +54,7 @@ _SIGNATURES = {
     "cer_bn_apply_nhwc": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int,
                                   c_int, _P]),
     "cer_bn_apply_nhwc_b3": (c_int, [_P] * 14 + [c_int] * 7 + [_P]),
+    "cer_bn_apply_nhwc_n16": (c_int, [_P] * 13 + [c_int] * 8 + [_P]),
     "cer_pack_conv_weight": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cer_weight_norm_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "cer_weight_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),

@@ -31,6 +31,9 @@ struct ConvArgs {
     int x_nchw, res_stride, Hr, Wr, act1, act2;
     float slope;
     int Kpad, M, tiles_m, tiles_n, steps, steps_per_split, split_k, cin_steps;
+    // narrow storage (cer_conv_desc.storage): 0 = fp32 / split tensors as the pointers say; CER_STORE_BF16 / CER_STORE_F16 =
+    // every 16-bit tensor of the launch (x_hi, w_hi, res_hi, y_hi) is ONE plane of that type and the *_lo pointers are NULL
+    int narrow;
 };
 
 template <int I> struct IdxC { static constexpr int v = I; };
@@ -51,6 +54,32 @@ __device__ __forceinline__ void split_bf16(float v, uint16_t &hi, uint16_t &lo) 
     hi = f32_to_bf16(v);
     lo = f32_to_bf16(v - bf16_to_f32(hi));
 }
+// one 16-bit plane: bf16 (CER_STORE_BF16) or IEEE half (CER_STORE_F16), round-to-nearest-even
+__device__ __forceinline__ uint16_t f32_to_f16(float f) {
+    const _Float16 h = (_Float16)f;
+    return __builtin_bit_cast(uint16_t, h);
+}
+__device__ __forceinline__ float f16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ uint16_t f32_to_n16(float f, int narrow) { return narrow == CER_STORE_F16 ? f32_to_f16(f) : f32_to_bf16(f); }
+__device__ __forceinline__ float n16_to_f32(uint16_t h, int narrow) { return narrow == CER_STORE_F16 ? f16_to_f32(h) : bf16_to_f32(h); }
+__device__ __forceinline__ void store_narrow4(uint16_t *dst, const float o[4], int narrow) {
+    ushort4 h;
+    if (narrow == CER_STORE_F16) {
+        h.x = f32_to_f16(o[0]); h.y = f32_to_f16(o[1]); h.z = f32_to_f16(o[2]); h.w = f32_to_f16(o[3]);
+    } else {
+        h.x = f32_to_bf16(o[0]); h.y = f32_to_bf16(o[1]); h.z = f32_to_bf16(o[2]); h.w = f32_to_bf16(o[3]);
+    }
+    *reinterpret_cast<ushort4 *>(dst) = h;
+}
+__device__ __forceinline__ void load_narrow4(const uint16_t *src, float o[4], int narrow) {
+    const ushort4 h = *reinterpret_cast<const ushort4 *>(src);
+    if (narrow == CER_STORE_F16) {
+        o[0] = f16_to_f32(h.x); o[1] = f16_to_f32(h.y); o[2] = f16_to_f32(h.z); o[3] = f16_to_f32(h.w);
+    } else {
+        o[0] = bf16_to_f32(h.x); o[1] = bf16_to_f32(h.y); o[2] = bf16_to_f32(h.z); o[3] = bf16_to_f32(h.w);
+    }
+}
+
 __device__ __forceinline__ void store_split4(uint16_t *hi, uint16_t *lo, const float o[4]) {
     ushort4 h, l;
     split_bf16(o[0], h.x, l.x); split_bf16(o[1], h.y, l.y);
@@ -110,6 +139,8 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c,
         if (p.res) {
             float4 r = *reinterpret_cast<const float4 *>(p.res + roff + c);
             rr[0] = r.x; rr[1] = r.y; rr[2] = r.z; rr[3] = r.w;
+        } else if (p.res_hi && p.narrow) {
+            load_narrow4(p.res_hi + roff + c, rr, p.narrow);
         } else if (p.res_hi) {
             const ushort4 h = *reinterpret_cast<const ushort4 *>(p.res_hi + roff + c);
             const ushort4 l = *reinterpret_cast<const ushort4 *>(p.res_lo + roff + c);
@@ -129,7 +160,10 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c,
         }
         if (p.aux) *reinterpret_cast<float4 *>(p.aux + doff) = make_float4(u[0], u[1], u[2], u[3]);
         if (p.y) *reinterpret_cast<float4 *>(p.y + yoff) = make_float4(o[0], o[1], o[2], o[3]);
-        if (p.y_hi) store_split4(p.y_hi + yoff, p.y_lo + yoff, o);
+        if (p.y_hi) {
+            if (p.narrow) store_narrow4(p.y_hi + yoff, o, p.narrow);
+            else store_split4(p.y_hi + yoff, p.y_lo + yoff, o);
+        }
         if (p.y2_hi) {
             const float4 s2 = *reinterpret_cast<const float4 *>(p.s2 + c), t2 = *reinterpret_cast<const float4 *>(p.t2 + c);
             float o2[4] = {o[0] * s2.x + t2.x, o[1] * s2.y + t2.y, o[2] * s2.z + t2.z, o[3] * s2.w + t2.w};
@@ -144,10 +178,12 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c,
                 if (p.mask) t *= p.mask[doff + e];
                 if (p.aux) p.aux[doff + e] = t;
                 if (p.res) t += p.res[roff + c + e];
+                else if (p.res_hi && p.narrow) t += n16_to_f32(p.res_hi[roff + c + e], p.narrow);
                 else if (p.res_hi) t += bf16_to_f32(p.res_hi[roff + c + e]) + bf16_to_f32(p.res_lo[roff + c + e]);
                 const float o = act_apply(t, p.act2, 0.f, p.slope);
                 if (p.y) p.y[yoff + e] = o;
-                if (p.y_hi) split_bf16(o, p.y_hi[yoff + e], p.y_lo[yoff + e]);
+                if (p.y_hi && p.narrow) p.y_hi[yoff + e] = f32_to_n16(o, p.narrow);
+                else if (p.y_hi) split_bf16(o, p.y_hi[yoff + e], p.y_lo[yoff + e]);
                 if (p.y2_hi) split_bf16(o * p.s2[c + e] + p.t2[c + e], p.y2_hi[yoff + e], p.y2_lo[yoff + e]);
             }
         }

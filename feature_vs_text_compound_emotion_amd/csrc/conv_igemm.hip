@@ -402,9 +402,6 @@ static void tile_dims(int tile, int &bm, int &bn) {
         case 1: bm = 128; bn = 128; break;
         case 2: bm = 128; bn = 64; break;
         case 4: bm = 64; bn = 128; break;
-        case 7: bm = 128; bn = 128; break;
-        case 8: bm = 128; bn = 64; break;
-        case 9: bm = 64; bn = 128; break;
         default: bm = 64; bn = 64; break;
     }
 }
@@ -416,10 +413,6 @@ static int launch_shape(int shape, const ConvArgs &a, bool vec, hipStream_t st) 
         case 2: return launch_cfg<128, 64, 2, 2, VAR>(a, vec, st);
         case 4: return launch_cfg<64, 128, 1, 4, VAR>(a, vec, st);
         case 5: return launch_cfg<64, 64, 2, 2, VAR>(a, vec, st);
-        case 6: return launch_cfg<64, 64, 1, 1, VAR, 16>(a, vec, st);    // one wave per block: no block barrier
-        case 7: return launch_cfg<128, 128, 2, 2, VAR, 16>(a, vec, st);  // BK = 16
-        case 8: return launch_cfg<128, 64, 2, 2, VAR, 16>(a, vec, st);
-        case 9: return launch_cfg<64, 128, 1, 4, VAR, 16>(a, vec, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_fwd: unknown tile id");
     }
 }
@@ -447,18 +440,21 @@ static int validate_desc(const cer_conv_desc *d) {
 
 namespace cer {
 int conv_b3_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, int &bk);
+int conv_n16_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, int &bk);
 }
 
-extern "C" int cer_conv2d_stats_tiles(const cer_conv_desc *d, int bf16x3) {
+extern "C" int cer_conv2d_stats_tiles(const cer_conv_desc *d, int kernel_family) {
     if (!d || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0) return 0;
     const int M = d->N * d->Ho * d->Wo;
     int bm, bn, bk;
-    if (bf16x3) {
+    if (kernel_family == 2) {
+        if (!conv_n16_tile_dims(d->tile, d->Cout, M, cer_conv_kpad(d->KH, d->KW, d->Cin), bm, bn, bk)) return 0;
+    } else if (kernel_family == 1) {
         const int t = conv_b3_tile_dims(d->tile, d->Cout, M, cer_conv_kpad(d->KH, d->KW, d->Cin), bm, bn, bk);
         if (!t) return 0;
         if (t == 6) return 2 * ((M + bm - 1) / bm);  // the ping-pong kernel writes one row per pixel half-tile
     } else {
-        tile_dims(pick_tile(d, M) % 10, bm, bn);
+        tile_dims(pick_tile(d, M), bm, bn);
     }
     return (M + bm - 1) / bm;
 }
@@ -469,8 +465,8 @@ extern "C" size_t cer_conv2d_workspace_bytes(const cer_conv_desc *d) {
 }
 
 namespace cer {
-int conv_b3_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, int &bk);
 int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st);
+int conv_n16_launch(int tile, const ConvArgs &a, hipStream_t st);
 }  // namespace cer
 
 extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, void *workspace, size_t workspace_bytes,
@@ -478,8 +474,18 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
     int rc = validate_desc(d);
     if (rc) return rc;
     if (!io) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: io block is NULL");
-    const bool b3 = io->x_hi != nullptr;
-    if (b3) {
+    if (d->storage != CER_STORE_NONE && d->storage != CER_STORE_BF16 && d->storage != CER_STORE_F16)
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: unknown storage type");
+    const bool narrow = d->storage != CER_STORE_NONE;
+    const bool n16 = narrow && io->x_hi != nullptr;   // narrow operands -> conv_n16 kernels
+    const bool b3 = !narrow && io->x_hi != nullptr;   // split operands -> bf16x3 kernels
+    if (narrow && (io->x_lo || io->w_lo || io->y_lo || io->res_lo || io->y2_hi || io->y2_lo))
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (narrow): 16-bit tensors are single planes (every *_lo and y2 pointer must be NULL)");
+    if (n16) {
+        if (!io->w_hi) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (narrow): x_hi and w_hi must both be given");
+        if (io->in_scale || io->mask || io->aux || d->x_nchw)
+            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow): no input affine / mask / aux / NCHW input");
+    } else if (b3) {
         if (!io->x_lo || !io->w_hi || !io->w_lo)
             return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3): x_hi, x_lo, w_hi, w_lo must all be given");
         if (io->in_scale || io->mask || io->aux || d->x_nchw)
@@ -490,8 +496,8 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
     if (!io->y && !io->y_hi && !io->y2_hi) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: no output tensor");
     if ((io->in_scale == nullptr) != (io->in_shift == nullptr))
         return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: in_scale and in_shift go together");
-    if ((io->y_hi == nullptr) != (io->y_lo == nullptr) || (io->res_hi == nullptr) != (io->res_lo == nullptr) ||
-        (io->y2_hi == nullptr) != (io->y2_lo == nullptr) || (io->y2_hi && (!io->s2 || !io->t2)))
+    if (!narrow && ((io->y_hi == nullptr) != (io->y_lo == nullptr) || (io->res_hi == nullptr) != (io->res_lo == nullptr) ||
+                    (io->y2_hi == nullptr) != (io->y2_lo == nullptr) || (io->y2_hi && (!io->s2 || !io->t2))))
         return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: split tensors need both planes (and s2/t2 for the second output)");
     if (io->residual && io->res_hi) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: give the residual as fp32 OR split");
     if (d->act1 == CER_ACT_PRELU && !io->alpha) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: PReLU needs alpha");
@@ -510,6 +516,7 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
     a.res_hi = io->res_hi; a.res_lo = io->res_lo; a.y_hi = io->y_hi; a.y_lo = io->y_lo;
     a.s2 = io->s2; a.t2 = io->t2; a.y2_hi = io->y2_hi; a.y2_lo = io->y2_lo;
     a.bias9 = io->bias9;
+    a.narrow = d->storage;
     if (io->bias9 && (io->bias || d->stride != 1 || d->Ho != d->H || d->Wo != d->W || d->H < 2 || d->W < 2 || d->split_k > 1))
         return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: bias9 replaces bias and needs a stride-1 same conv on >= 2x2 images without split-K");
     a.x_ld = d->x_ld > 0 ? d->x_ld : d->Cin;
@@ -526,7 +533,13 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
     a.M = d->N * d->Ho * d->Wo;
     const bool vec = (d->Cin % 32) == 0;
     int tile, bm, bn, bk, esz;
-    if (b3) {
+    if (n16) {
+        tile = conv_n16_tile_dims(d->tile, d->Cout, a.M, a.Kpad, bm, bn, bk);
+        if (!tile) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (narrow): unknown tile id");
+        if (d->Cin % bk != 0 || (a.x_ld & 7))
+            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow): Cin must be a multiple of 64 and x_ld of 8");
+        esz = 2;
+    } else if (b3) {
         tile = conv_b3_tile_dims(d->tile, d->Cout, a.M, a.Kpad, bm, bn, bk);
         if (!tile) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3): unknown tile id");
         if (d->Cin % bk != 0 || (a.x_ld & 7))
@@ -534,18 +547,19 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
         esz = 2;
     } else {
         tile = pick_tile(d, a.M);
-        bk = (tile % 10 >= 6) ? 16 : 32;
-        tile_dims(tile % 10, bm, bn);
+        if (tile != 1 && tile != 2 && tile != 4 && tile != 5) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: unknown tile id");
+        bk = 32;
+        tile_dims(tile, bm, bn);
         esz = 4;
     }
-    a.cin_steps = (vec || b3) ? d->Cin / bk : 1;
+    a.cin_steps = (vec || b3 || n16) ? d->Cin / bk : 1;
     a.steps = a.Kpad / bk;
     a.split_k = d->split_k > a.steps ? a.steps : d->split_k;
     a.steps_per_split = (a.steps + a.split_k - 1) / a.split_k;
     a.split_k = (a.steps + a.steps_per_split - 1) / a.steps_per_split;
     a.tiles_m = (a.M + bm - 1) / bm;
     a.tiles_n = (a.Cout + bn - 1) / bn;
-    if (vec || b3) {
+    if (vec || b3 || n16) {
         // the staging path addresses x and w as scalar base + 32-bit per-thread byte offset
         if (d->KH * d->KW > 32) return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d: more than 32 filter taps");
         // the per-row offsets are UNSIGNED distances from the tile's first row: output pixels must map to non-decreasing
@@ -565,21 +579,14 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
         if (!workspace || workspace_bytes < need) return cer_set_error(CER_ERR_WORKSPACE, "conv2d: split-K workspace too small");
         a.y = (float *)workspace;
     }
-    if (b3) {
+    if (n16) {
+        rc = conv_n16_launch(tile, a, st);
+    } else if (b3) {
         rc = conv_b3_launch(tile, a, st);
     } else {
-        // tile = shape + 10*v: v = 0 -> shipped variant (single LDS buffer); v = 1 -> double buffered;
-        // v = 2 -> double buffered + setprio; 3..6 -> other A/B and timing-only ablation builds
-        switch (tile / 10) {
-            case 0: rc = launch_shape<2>(tile % 10, a, vec, st); break;
-            case 1: rc = launch_shape<0>(tile % 10, a, vec, st); break;
-            case 2: rc = launch_shape<1>(tile % 10, a, vec, st); break;
-            case 3: rc = launch_shape<6>(tile % 10, a, vec, st); break;   // single buffer + per-block priority
-            case 4: rc = launch_shape<2>(tile % 10, a, vec, st); break;   // single buffer, no setprio
-            case 5: rc = launch_shape<2 + 8>(tile % 10, a, vec, st); break;        // ablation: no staging in the loop
-            case 6: rc = launch_shape<2 + 8 + 16>(tile % 10, a, vec, st); break;   // ablation: no staging, no barriers
-            default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: unknown tile variant");
-        }
+        // the shipped variant: single LDS buffer (VAR 2).  The double-buffered / setprio / BK = 16 / ablation builds that
+        // were measured against it in round 1 are in the history (they were 96 instantiations and most of the build time)
+        rc = launch_shape<2>(tile, a, vec, st);
     }
     if (rc) return rc;
     if (a.split_k > 1) {

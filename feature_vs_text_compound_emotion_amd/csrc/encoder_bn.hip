@@ -154,6 +154,125 @@ __global__ __launch_bounds__(256) void bn_apply_nhwc_kernel(ApplyArgs p) {
     }
 }
 
+// ---- narrow (single 16-bit plane) variant: 8 channels per thread = 16-byte loads / stores of the narrow tensors ----
+struct ApplyArgsN16 {
+    const float *y;          // conv result as fp32 ...
+    const uint16_t *y16;     // ... or as a narrow plane (exactly one of the two)
+    const float *scale, *shift, *alpha, *res, *res_scale, *res_shift, *mask;
+    const uint16_t *res16;   // residual as a narrow plane (alternative to res)
+    float *out, *stats;
+    uint16_t *out16;
+    int P, Ho, Wo, C, res_stride, Hr, Wr, rows_per_block, narrow;
+};
+
+__device__ __forceinline__ void load8(const float *p, float v[8]) {
+    const float4 a = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8_n16(const uint16_t *p, float v[8], int narrow) {
+    const uint4 q = *reinterpret_cast<const uint4 *>(p);
+    const unsigned w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = n16_to_f32((uint16_t)(w[i] & 0xffffu), narrow);
+        v[2 * i + 1] = n16_to_f32((uint16_t)(w[i] >> 16), narrow);
+    }
+}
+__device__ __forceinline__ void store8_n16(uint16_t *p, const float v[8], int narrow) {
+    unsigned w[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) w[i] = (unsigned)f32_to_n16(v[2 * i], narrow) | ((unsigned)f32_to_n16(v[2 * i + 1], narrow) << 16);
+    *reinterpret_cast<uint4 *>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+__global__ __launch_bounds__(256) void bn_apply_n16_kernel(ApplyArgsN16 p) {
+    __shared__ float red[2][256][8];
+    const int c8n = p.C >> 3;                    // 8-channel groups per row (8..128)
+    const int rpp = 256 / c8n;                   // rows per pass
+    const int tc = threadIdx.x % c8n, tr = threadIdx.x / c8n;
+    const int c = tc * 8;
+    float sc[8], sh[8], al[8], rs[8], rt[8];
+    load8(p.scale + c, sc);
+    load8(p.shift + c, sh);
+    if (p.alpha) load8(p.alpha + c, al);
+    if (p.res_scale) {
+        load8(p.res_scale + c, rs);
+        load8(p.res_shift + c, rt);
+    }
+    float s1[8], s2[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+    const int row0 = blockIdx.x * p.rows_per_block;
+    for (int r = row0 + tr; r < min(p.P, row0 + p.rows_per_block); r += rpp) {
+        const size_t off = (size_t)r * p.C + c;
+        float o[8];
+        if (p.y16) load8_n16(p.y16 + off, o, p.narrow);
+        else load8(p.y + off, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = o[e] * sc[e] + sh[e];
+        if (p.alpha) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = o[e] >= 0.f ? o[e] : o[e] * al[e];
+        }
+        if (p.mask) {
+            float m[8];
+            load8(p.mask + off, m);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] *= m[e];
+        }
+        if (p.res || p.res16) {
+            size_t roff;
+            if (p.res_stride == 1 && p.Hr == p.Ho && p.Wr == p.Wo) {
+                roff = off;
+            } else {
+                const int hw = p.Ho * p.Wo;
+                const int n = r / hw, q = r - n * hw;
+                const int ho = q / p.Wo, wo = q - ho * p.Wo;
+                roff = ((size_t)(n * p.Hr + ho * p.res_stride) * p.Wr + wo * p.res_stride) * p.C + c;
+            }
+            float x[8];
+            if (p.res) load8(p.res + roff, x);
+            else load8_n16(p.res16 + roff, x, p.narrow);
+            if (p.res_scale) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += x[e] * rs[e] + rt[e];
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) o[e] += x[e];
+            }
+        }
+        if (p.out) {
+            *reinterpret_cast<float4 *>(p.out + off) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4 *>(p.out + off + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        }
+        if (p.out16) store8_n16(p.out16 + off, o, p.narrow);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1[e] += o[e]; s2[e] += o[e] * o[e]; }
+    }
+    if (!p.stats) return;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { red[0][threadIdx.x][e] = s1[e]; red[1][threadIdx.x][e] = s2[e]; }
+    __syncthreads();
+    if (threadIdx.x < c8n) {
+        float a1[8], a2[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a1[e] = a2[e] = 0.f;
+        for (int t = 0; t < rpp; ++t) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                a1[e] += red[0][t * c8n + threadIdx.x][e];
+                a2[e] += red[1][t * c8n + threadIdx.x][e];
+            }
+        }
+        float *dst = p.stats + (size_t)blockIdx.x * 2 * p.C;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            dst[threadIdx.x * 8 + e] = a1[e];
+            dst[p.C + threadIdx.x * 8 + e] = a2[e];
+        }
+    }
+}
+
 }  // namespace cer
 
 using namespace cer;
@@ -227,4 +346,27 @@ extern "C" int cer_bn_apply_nhwc_b3(const float *y, const float *scale, const fl
                                     float *stats, int N, int Ho, int Wo, int C, int res_stride, int Hr, int Wr, void *stream) {
     return bn_apply_launch(y, scale, shift, alpha, res, res_hi, res_lo, res_scale, res_shift, mask, out, out_hi, out_lo, stats,
                            N, Ho, Wo, C, res_stride, Hr, Wr, stream);
+}
+
+extern "C" int cer_bn_apply_nhwc_n16(const float *y, const uint16_t *y16, const float *scale, const float *shift,
+                                     const float *alpha, const float *res, const uint16_t *res16, const float *res_scale,
+                                     const float *res_shift, const float *mask, float *out, uint16_t *out16, float *stats,
+                                     int N, int Ho, int Wo, int C, int res_stride, int Hr, int Wr, int storage, void *stream) {
+    if ((y == nullptr) == (y16 == nullptr) || !scale || !shift || (!out && !out16) || N <= 0 || Ho <= 0 || Wo <= 0 || C < 64 ||
+        C > 2048 || (C & 7) || (256 % (C / 8)) != 0)
+        return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc_n16: one of y / y16; C must be 64..2048 with C/8 dividing 256");
+    if (storage != CER_STORE_BF16 && storage != CER_STORE_F16)
+        return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc_n16: storage must be bf16 or f16");
+    if ((long long)N * Ho * Wo >= (1ll << 31)) return cer_set_error(CER_ERR_UNSUPPORTED, "bn_apply_nhwc_n16: too many pixels");
+    if (res && res16) return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc_n16: residual is fp32 OR narrow");
+    const bool has_res = res || res16;
+    if ((res_scale == nullptr) != (res_shift == nullptr) || (res_scale && !has_res))
+        return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc_n16: residual affine needs a residual, res_scale and res_shift");
+    if (has_res && (res_stride <= 0 || (Ho - 1) * res_stride >= Hr || (Wo - 1) * res_stride >= Wr))
+        return cer_set_error(CER_ERR_INVALID_ARG, "bn_apply_nhwc_n16: residual geometry out of range");
+    ApplyArgsN16 a{y, y16, scale, shift, alpha, res, res_scale, res_shift, mask, res16, out, stats, out16,
+                   N * Ho * Wo, Ho, Wo, C, res_stride, Hr, Wr, apply_rows_per_block(N * Ho * Wo), storage};
+    CER_LAUNCH(bn_apply_n16_kernel, dim3(cer_bn_apply_stats_tiles(a.P)), dim3(256), 0, (hipStream_t)stream, a);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
 }

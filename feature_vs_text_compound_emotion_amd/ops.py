@@ -9,7 +9,8 @@ import os
 import torch
 
 from . import _lib
-from ._lib import ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_PRELU, ACT_RELU, ConvDesc, ConvIO, check, current_stream, ptr  # noqa: F401
+from ._lib import (ACT_GELU, ACT_LEAKY, ACT_NONE, ACT_PRELU, ACT_RELU, STORE_BF16, STORE_F16, STORE_NONE, ConvDesc,  # noqa: F401
+                   ConvIO, check, current_stream, ptr)
 
 LEAKY_SLOPE = 0.01
 
@@ -55,7 +56,7 @@ def pack_conv_weight(w_oihw, out_scale=None, flip=False, transpose=False):
 def conv2d(x, w_packed, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, in_scale=None,
            in_shift=None, bias=None, alpha=None, residual=None, res_stride=1, mask=None, act1=ACT_NONE,
            act2=ACT_NONE, slope=LEAKY_SLOPE, split_k=1, x_nchw=False, tile=0, out=None, aux=None, x_ld=0, y_ld=0,
-           x_shape=None, want_stats=False, out_split=False, next_affine=None, want_f32=True):
+           x_shape=None, want_stats=False, out_split=False, next_affine=None, want_f32=True, out_n16=None):
     """y[N,Ho,Wo,Cout] = act2(mask*act1(conv(affine(x), w)+bias) + residual).  x is NHWC
     (or NCHW with ``x_nchw`` on the small-Cin path).  ``x_shape`` = (N,H,W,Cin) overrides
     x.shape when x is a column slice (then ``x_ld`` is its row pitch)."""
@@ -105,6 +106,20 @@ def conv2d(x, w_packed, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None
     ws_bytes = lib.cer_conv2d_workspace_bytes(ctypes.byref(d))
     ws = _empty((ws_bytes // 4,), x) if ws_bytes else None
     stats = _empty((lib.cer_conv2d_stats_tiles(ctypes.byref(d), 0), 2, cout), x) if want_stats else None
+    if out_n16 is not None:  # fp32 kernel, narrow (single bf16 / half plane) output: the Cin = 3 stem of the narrow encoder
+        if out_split or next_affine is not None:
+            raise ValueError("out_n16 excludes the split outputs")
+        io = ConvIO()
+        io.x, io.w = x.data_ptr(), w_packed.data_ptr()
+        for name, t in (("in_scale", in_scale), ("in_shift", in_shift), ("bias", bias), ("alpha", alpha),
+                        ("residual", residual), ("mask", mask), ("y", out), ("aux", aux), ("stats", stats)):
+            if t is not None:
+                setattr(io, name, t.data_ptr())
+        d.storage = storage_of(out_n16)
+        res = {"y": out, "stats": stats, "n16": torch.empty((n, ho, wo, cout), device=x.device, dtype=out_n16)}
+        io.y_hi = res["n16"].data_ptr()
+        check(lib.cer_conv2d_run(ctypes.byref(d), ctypes.byref(io), ptr(ws), ws_bytes, current_stream()), "cer_conv2d_run")
+        return res
     if not (out_split or next_affine is not None):
         check(lib.cer_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w_packed), ptr(in_scale), ptr(in_shift), ptr(bias),
                                  ptr(alpha), ptr(residual), ptr(mask), ptr(out), ptr(aux), ptr(stats), ptr(ws), ws_bytes,
@@ -254,6 +269,157 @@ def conv2d_b3(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bi
             4.0 * cout * cin * kh * kw + (4.0 * nout if residual is not None else 0.0)
         CONV_TRACE.append((lib.cer_conv2d_b3_tile(ctypes.byref(d)), 2.0 * n * ho * wo * cout * cin * kh * kw, e0, e1, nbytes))
     return res
+
+
+# ------------------------------------------------------------------ narrow storage (one bf16 / half plane per tensor)
+def storage_of(dtype):
+    """torch dtype -> cer_storage of the narrow kernels."""
+    if dtype == torch.bfloat16:
+        return STORE_BF16
+    if dtype == torch.float16:
+        return STORE_F16
+    raise ValueError(f"narrow storage is torch.bfloat16 or torch.float16, got {dtype}")
+
+
+def _dev_n16(t, name, dtype=None):
+    if t is None:
+        return
+    if not (t.is_cuda and t.dtype in (torch.bfloat16, torch.float16) and t.is_contiguous()) or (dtype is not None and t.dtype != dtype):
+        raise ValueError(f"{name}: expected a contiguous {dtype or 'bfloat16/float16'} GPU tensor, got {t.dtype} {t.device}")
+
+
+def to_n16(x, dtype, scale=None, shift=None):
+    """fp32 tensor -> narrow tensor (round-to-nearest-even), optionally after x*scale[c]+shift[c] over the last axis."""
+    _dev_f32(x, "x")
+    _dev_f32(scale, "scale")
+    _dev_f32(shift, "shift")
+    out = torch.empty(x.shape, device=x.device, dtype=dtype)
+    c = x.shape[-1] if scale is not None else 0
+    check(_lib.load().cer_to_n16(ptr(x), ptr(scale), ptr(shift), c, ptr(out), x.numel(), storage_of(dtype), current_stream()),
+          "cer_to_n16")
+    return out
+
+
+def from_n16(x):
+    _dev_n16(x, "x")
+    out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    check(_lib.load().cer_from_n16(ptr(x), ptr(out), x.numel(), storage_of(x.dtype), current_stream()), "cer_from_n16")
+    return out
+
+
+def conv2d_n16(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bias=None, alpha=None, residual=None,
+               res_stride=1, act1=ACT_NONE, act2=ACT_NONE, slope=LEAKY_SLOPE, split_k=1, tile=0, out_f32=False,
+               out_n16=True, want_stats=False, bias9=None):
+    """Narrow convolution: x [N,H,W,Cin] and w [Cout,Kpad] are bf16 / float16 tensors of the same dtype (one MFMA per
+    product, fp32 accumulate); residual: narrow or fp32.  Returns a dict with 'n16' (narrow output), 'y' (fp32), 'stats'."""
+    lib = _lib.load()
+    _dev_n16(x, "x")
+    _dev_n16(w, "w", x.dtype)
+    _dev_f32(bias, "bias")
+    _dev_f32(alpha, "alpha")
+    n, h, wd, cin = x.shape
+    cout = w.shape[0]
+    if w.shape[1] != conv_kpad(kh, kw, cin):
+        raise ValueError(f"packed weight has K={w.shape[1]}, expected {conv_kpad(kh, kw, cin)}")
+    if out_hw is None:
+        ho = (h + 2 * pad[0] - dil[0] * (kh - 1) - 1) // stride + 1
+        wo = (wd + 2 * pad[1] - dil[1] * (kw - 1) - 1) // stride + 1
+    else:
+        ho, wo = out_hw
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Ho, d.Wo, d.Cout = n, h, wd, cin, ho, wo, cout
+    d.KH, d.KW, d.stride, d.dil_h, d.dil_w, d.pad_t, d.pad_l = kh, kw, stride, dil[0], dil[1], pad[0], pad[1]
+    d.res_stride, d.Hr, d.Wr = res_stride, 0, 0
+    d.act1, d.act2, d.slope, d.split_k, d.tile = act1, act2, slope, split_k, tile
+    d.storage = storage_of(x.dtype)
+    io = ConvIO()
+    io.x_hi, io.w_hi = x.data_ptr(), w.data_ptr()
+    io.bias = bias.data_ptr() if bias is not None else None
+    io.alpha = alpha.data_ptr() if alpha is not None else None
+    if bias9 is not None:
+        _dev_f32(bias9, "bias9")
+        if tuple(bias9.shape) != (9, cout):
+            raise ValueError("bias9 must be [9, Cout]")
+        io.bias9 = bias9.data_ptr()
+    if residual is not None:
+        rshape = residual.shape
+        if rshape[0] != n or rshape[3] != cout:
+            raise ValueError("residual shape does not match the output")
+        d.Hr, d.Wr = rshape[1], rshape[2]
+        if residual.dtype == torch.float32:
+            _dev_f32(residual, "residual")
+            io.residual = residual.data_ptr()
+        else:
+            _dev_n16(residual, "residual", x.dtype)
+            io.res_hi = residual.data_ptr()
+    res = {}
+    dev = x.device
+    if out_f32:
+        res["y"] = torch.empty((n, ho, wo, cout), device=dev, dtype=torch.float32)
+        io.y = res["y"].data_ptr()
+    if out_n16:
+        res["n16"] = torch.empty((n, ho, wo, cout), device=dev, dtype=x.dtype)
+        io.y_hi = res["n16"].data_ptr()
+    if want_stats:
+        res["stats"] = torch.empty((lib.cer_conv2d_stats_tiles(ctypes.byref(d), 2), 2, cout), device=dev, dtype=torch.float32)
+        io.stats = res["stats"].data_ptr()
+    ws_bytes = lib.cer_conv2d_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty((ws_bytes // 4,), device=dev, dtype=torch.float32) if ws_bytes else None
+    if CONV_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    check(lib.cer_conv2d_run(ctypes.byref(d), ctypes.byref(io), ptr(ws), ws_bytes, current_stream()), "cer_conv2d_run")
+    if CONV_TRACE is not None:
+        e1.record()
+        # algorithmic bytes: narrow input + every output tensor written + narrow weights + residual read
+        nout = n * ho * wo * cout
+        nbytes = 2.0 * n * h * wd * cin + nout * (4.0 * int(out_f32) + 2.0 * int(out_n16)) + 2.0 * cout * cin * kh * kw + \
+            (0.0 if residual is None else (4.0 if residual.dtype == torch.float32 else 2.0) * nout)
+        CONV_TRACE.append((lib.cer_conv2d_n16_tile(ctypes.byref(d)), 2.0 * n * ho * wo * cout * cin * kh * kw, e0, e1, nbytes))
+    return res
+
+
+def bn_apply_nhwc_n16(y, scale, shift, dtype=None, alpha=None, res=None, res_stride=1, res_scale=None, res_shift=None, mask=None,
+                      want_stats=False, out_f32=False, out_n16=True):
+    """``bn_apply_nhwc`` for the narrow encoder: ``y`` (the conv result) and ``res`` are fp32 or narrow tensors; the result
+    comes back narrow ('n16', what the next conv reads) and/or fp32 ('y'); 'stats' as requested."""
+    for t, nme in ((scale, "scale"), (shift, "shift"), (alpha, "alpha"), (res_scale, "res_scale"), (res_shift, "res_shift"),
+                   (mask, "mask")):
+        _dev_f32(t, nme)
+    n, ho, wo, c = y.shape
+    lib = _lib.load()
+    if dtype is None:
+        dtype = y.dtype if y.dtype != torch.float32 else (res.dtype if res is not None else None)
+    if dtype is None or dtype == torch.float32:
+        raise ValueError("bn_apply_nhwc_n16: pass dtype= when neither y nor res is a narrow tensor")
+    y32 = y16 = r32 = r16 = None
+    if y.dtype == torch.float32:
+        _dev_f32(y, "y")
+        y32 = y
+    else:
+        _dev_n16(y, "y", dtype)
+        y16 = y
+    hr = wr = 0
+    if res is not None:
+        hr, wr = res.shape[1], res.shape[2]
+        if res.dtype == torch.float32:
+            _dev_f32(res, "res")
+            r32 = res
+        else:
+            _dev_n16(res, "res", dtype)
+            r16 = res
+    out = {}
+    if out_f32:
+        out["y"] = torch.empty(tuple(y.shape), device=y.device, dtype=torch.float32)
+    if out_n16:
+        out["n16"] = torch.empty(tuple(y.shape), device=y.device, dtype=dtype)
+    if want_stats:
+        out["stats"] = _empty((lib.cer_bn_apply_stats_tiles(n * ho * wo), 2, c), scale)
+    check(lib.cer_bn_apply_nhwc_n16(ptr(y32), ptr(y16), ptr(scale), ptr(shift), ptr(alpha), ptr(r32), ptr(r16), ptr(res_scale),
+                                    ptr(res_shift), ptr(mask), ptr(out.get("y")), ptr(out.get("n16")), ptr(out.get("stats")),
+                                    n, ho, wo, c, res_stride, hr, wr, storage_of(dtype), current_stream()),
+          "cer_bn_apply_nhwc_n16")
+    return out
 
 
 AUTO_SPLIT_K = os.environ.get("CER_TAIL_SPLITK", "1") != "0"

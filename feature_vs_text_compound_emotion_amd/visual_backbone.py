@@ -184,19 +184,26 @@ class IR50(nn.Module):
         self._packed_train = None
         self._packed_train_key = None
         self.bn_mode = "reference"  # or "frozen": encoder BatchNorm/Dropout stay in eval behaviour under train()
-        # "bf16x3": split hi/lo bf16 operands, 3 bf16 MFMAs per product (fp32-class accuracy, logit error
-        # ~1e-6, 2-2.5x faster); "fp32": the exact-fp32 MFMA kernels
+        # "bf16x3": split hi/lo bf16 operands, 3 bf16 MFMAs per product (<= 2^-15 relative per product, logit error
+        # ~1e-6, 2-2.5x faster than fp32); "fp32": the exact-fp32 MFMA kernels
         self.precision = "bf16x3"
         self._packed_b3 = None
         self._packed_b3_key = None
         self._packed_train_b3 = None
         self._packed_train_b3_key = None
+        # "bf16" / "fp16": narrow storage -- ONE 16-bit plane per tensor, one MFMA per product, fp32 accumulate and fp32
+        # epilogue arithmetic (csrc/conv_n16.hip): what the reference's --amp recipe computes (fp16 autocast,
+        # trainer.py:341,367) and BASELINE cfg5's "bf16 storage / fp32 accumulate"
+        self._packed_n16 = None
+        self._packed_n16_key = None
+        self._packed_train_n16 = None
+        self._packed_train_n16_key = None
         self.dropout_seed = 0
         self._dropout_calls = 0
 
     def __deepcopy__(self, memo):
         """trainer.py:656,705 deep-copies the model: copy parameters/buffers, not the packed caches."""
-        names = ("_packed", "_packed_train", "_packed_b3", "_packed_train_b3")
+        names = ("_packed", "_packed_train", "_packed_b3", "_packed_train_b3", "_packed_n16", "_packed_train_n16")
         caches = [getattr(self, n) for n in names]
         for n in names:
             setattr(self, n, None)
@@ -343,6 +350,155 @@ class IR50(nn.Module):
         self._packed_train_b3, self._packed_train_b3_key = P, key
         return P
 
+    # ------------------------------------------------------------------ narrow (bf16 / fp16 storage) packing and forward
+    NARROW = {"bf16": torch.bfloat16, "fp16": torch.float16}
+
+    def pack_n16(self, dtype):
+        """Eval-mode layouts for the narrow kernels: the same folds as ``pack_b3`` (post-conv BatchNorms as output scale +
+        bias, pre-conv BatchNorms through ``fold_input_bn_3x3``, the head's two BatchNorms into the FC), computed in fp32
+        and rounded ONCE to the storage type."""
+        key = (dtype, self._state_key())
+        if self._packed_n16 is not None and key == self._packed_n16_key:
+            return self._packed_n16
+        if self.input_layer[0].weight.device.type != "cuda":
+            raise RuntimeError("IR50 runs on the HIP kernels only: move the module to a GPU (no CPU fallback)")
+        P = {}
+        s, b = self._bn_affine(self.input_layer[1])
+        P["stem_w"] = ops.pack_conv_weight(self.input_layer[0].weight.detach().contiguous(), s)
+        P["stem_b"], P["stem_a"] = b, self.input_layer[2].weight.detach().contiguous()
+        units = []
+        for u in self.body:
+            d = {"stride": u.stride, "proj": u.cin != u.depth}
+            in_s, in_b = self._bn_affine(u.res_layer[0])
+            w1, d["b9"] = ops.fold_input_bn_3x3(u.res_layer[1].weight.detach(), in_s, in_b)
+            d["w1"] = ops.to_n16(w1, dtype)
+            d["a1"] = u.res_layer[2].weight.detach().contiguous()
+            s2, b2 = self._bn_affine(u.res_layer[4])
+            d["w2"] = ops.to_n16(ops.pack_conv_weight(u.res_layer[3].weight.detach().contiguous(), s2), dtype)
+            d["b2"] = b2
+            if d["proj"]:
+                ss, sb = self._bn_affine(u.shortcut_layer[1])
+                d["ws"] = ops.to_n16(ops.pack_conv_weight(u.shortcut_layer[0].weight.detach().contiguous(), ss), dtype)
+                d["bs"] = sb
+            units.append(d)
+        P["units"] = units
+        hw = self.head_hw
+        s0, t0 = self._bn_affine(self.output_layer[0])
+        s4, t4 = self._bn_affine(self.output_layer[4])
+        fc = self.output_layer[3]
+        w = fc.weight.detach().view(fc.out_features, -1, hw * hw).permute(0, 2, 1)  # K order (c,h,w) -> (h,w,c)
+        bias = fc.bias.detach() + (w * t0.view(1, 1, -1)).sum((1, 2))
+        w = (w * s0.view(1, 1, -1)).contiguous().view(fc.out_features, -1)
+        P["head_w"] = ops.to_n16((w * s4.view(-1, 1)).contiguous(), dtype)
+        P["head_b"] = (bias * s4 + t4).contiguous()
+        self._packed_n16, self._packed_n16_key = P, key
+        return P
+
+    def pack_train_n16(self, dtype):
+        key = (dtype, tuple((p.data_ptr(), p._version) for p in self.parameters()))
+        if self._packed_train_n16 is not None and key == self._packed_train_n16_key:
+            return self._packed_train_n16
+        if self.input_layer[0].weight.device.type != "cuda":
+            raise RuntimeError("IR50 runs on the HIP kernels only: move the module to a GPU (no CPU fallback)")
+        P = {"stem_w": ops.pack_conv_weight(self.input_layer[0].weight.detach().contiguous()), "units": []}
+        for u in self.body:
+            d = {"w1_f32": ops.pack_conv_weight(u.res_layer[1].weight.detach().contiguous()),
+                 "w2": ops.to_n16(ops.pack_conv_weight(u.res_layer[3].weight.detach().contiguous()), dtype)}
+            if u.cin != u.depth:
+                d["ws"] = ops.to_n16(ops.pack_conv_weight(u.shortcut_layer[0].weight.detach().contiguous()), dtype)
+            P["units"].append(d)
+        fc, hw = self.output_layer[3], self.head_hw
+        P["head_w"] = ops.to_n16(fc.weight.detach().view(fc.out_features, -1, hw * hw).permute(0, 2, 1).contiguous().view(
+            fc.out_features, -1), dtype)
+        self._packed_train_n16, self._packed_train_n16_key = P, key
+        return P
+
+    def _forward_n16(self, x, dtype):
+        """Eval / frozen forward on the narrow kernels (Cin = 3 stem on the fp32 small-Cin kernel, narrow output)."""
+        P = self.pack_n16(dtype)
+        xs = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), bias=P["stem_b"], alpha=P["stem_a"],
+                        act1=ops.ACT_PRELU, x_nchw=True, want_f32=False, out_n16=dtype)["n16"]
+        for d in P["units"]:
+            s = d["stride"]
+            t = ops.conv2d_n16(xs, d["w1"], 3, 3, pad=(1, 1), bias9=d["b9"], alpha=d["a1"], act1=ops.ACT_PRELU)["n16"]
+            if d["proj"]:
+                sc = ops.conv2d_n16(xs, d["ws"], 1, 1, stride=s, bias=d["bs"])["n16"]
+                xs = ops.conv2d_n16(t, d["w2"], 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=sc, res_stride=1)["n16"]
+            else:
+                xs = ops.conv2d_n16(t, d["w2"], 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=xs, res_stride=s)["n16"]
+        n, h, w, c = xs.shape
+        if h != self.head_hw or w != self.head_hw:
+            raise RuntimeError(f"IR50 head was built for {self.head_hw}x{self.head_hw} feature maps "
+                               f"({8 * self.head_hw}x{8 * self.head_hw} frames) but got {h}x{w}")
+        k = h * w * c
+        e = ops.conv2d_n16(xs.view(n, 1, 1, k), P["head_w"], 1, 1, bias=P["head_b"], split_k=self._head_split_k(n, k),
+                           out_f32=True, out_n16=False)["y"]
+        return ops.l2norm_rows(e.view(n, -1))
+
+    def _forward_batch_stats_n16(self, x, dtype, head_mask=None):
+        """Reference train() semantics (batch-statistics BatchNorm everywhere) on the narrow kernels.  Every activation
+        tensor -- including the raw conv results the BatchNorms normalise -- is stored as one 16-bit plane, exactly what
+        the reference's autocast does with its conv / batch_norm outputs; sums, statistics (taken from the fp32
+        accumulators, before the rounding), normalisation and the residual adds are fp32.  Structure as the bf16x3 path:
+        ONE bandwidth-bound ``bn_apply`` pass per unit (6 bytes per element instead of 12), the next unit's pre-conv
+        BatchNorm folded into its 3x3 conv."""
+        P = self.pack_train_n16(dtype)
+        self._packed = self._packed_b3 = self._packed_n16 = None  # running statistics are about to change
+        n = x.shape[0]
+        r = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True, want_f32=False, out_n16=dtype)
+        s, t = self._finalize(r["stats"], r["n16"].numel() // 64, self.input_layer[1])
+        r = ops.bn_apply_nhwc_n16(r["n16"], s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True)
+        ys, xst = r["n16"], r["stats"]
+        del r
+        plan = self._release_plan()
+        first_released = len(P["units"]) if plan is None else plan
+        y = None
+        for i, (u, d) in enumerate(zip(self.body, P["units"])):
+            if i >= first_released:  # released for training: exact-fp32 path with a backward
+                y = self._released_unit(u, y)
+                continue
+            last = i + 1 == first_released  # the next consumer (released unit or head) wants fp32
+            s1, t1 = self._finalize(xst, ys.numel() // u.cin, u.res_layer[0])
+            w1, b9 = ops.fold_input_bn_3x3(u.res_layer[1].weight.detach(), s1, t1)
+            tt = ops.conv2d_n16(ys, ops.to_n16(w1, dtype), 3, 3, pad=(1, 1), alpha=u.res_layer[2].weight.detach(),
+                                act1=ops.ACT_PRELU, bias9=b9)["n16"]
+            r = ops.conv2d_n16(tt, d["w2"], 3, 3, stride=u.stride, pad=(1, 1), want_stats=True)
+            del tt
+            z = r["n16"]
+            cnt = z.numel() // u.depth
+            s2, t2 = self._finalize(r["stats"], cnt, u.res_layer[4])
+            if u.cin != u.depth:
+                rs = ops.conv2d_n16(ys, d["ws"], 1, 1, stride=u.stride, want_stats=True)
+                ss, stt = self._finalize(rs["stats"], cnt, u.shortcut_layer[1])
+                o = ops.bn_apply_nhwc_n16(z, s2, t2, res=rs["n16"], res_scale=ss, res_shift=stt, want_stats=True,
+                                          out_f32=last, out_n16=not last)
+            else:
+                o = ops.bn_apply_nhwc_n16(z, s2, t2, res=ys, res_stride=u.stride, want_stats=True, out_f32=last,
+                                          out_n16=not last)
+            ys, xst, y = o.get("n16"), o["stats"], o.get("y")
+            del z, r, o
+        nn_, h, w, c = y.shape
+        if h != self.head_hw or w != self.head_hw:
+            raise RuntimeError(f"IR50 head was built for {self.head_hw}x{self.head_hw} feature maps but got {h}x{w}")
+        p_drop = self.output_layer[1].p
+        if head_mask is None and p_drop > 0:
+            self._dropout_calls += 1
+            head_mask = ops.dropout_mask(tuple(y.shape), p_drop, 0x1f50 + self.dropout_seed, self._dropout_calls * y.numel(),
+                                         y.device)
+        if plan is not None:
+            return self._released_head(y, head_mask)
+        s0, t0 = self._finalize(xst, y.numel() // c, self.output_layer[0])
+        hfeat = ops.bn_apply_nhwc_n16(y, s0, t0, dtype=dtype, mask=head_mask)["n16"]
+        k = h * w * c
+        fc, bn1 = self.output_layer[3], self.output_layer[4]
+        e = ops.conv2d_n16(hfeat.view(n, 1, 1, k), P["head_w"], 1, 1, bias=fc.bias.detach(),
+                           split_k=self._head_split_k(n, k), out_f32=True, out_n16=False)["y"].view(n, -1)
+        e, _, _ = ops.bn_rows_fwd(e, bn1.weight.detach(), bn1.bias.detach(), bn1.running_mean, bn1.running_var, True,
+                                  bn1.eps, bn1.momentum)
+        torch._foreach_add_([m.num_batches_tracked for m in self.modules()
+                             if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d))], 1)
+        return ops.l2norm_rows(e)
+
     def _forward_b3(self, x):
         """Eval / frozen forward on the bf16x3 kernels (Cin = 3 stem on the fp32 small-Cin kernel)."""
         P = self.pack_b3()
@@ -374,7 +530,7 @@ class IR50(nn.Module):
         the whole batch -- is folded into its 3x3 conv (input scale into the weights, input shift into a
         border-dependent bias, ``ops.fold_input_bn_3x3``), so no re-split pass over the activations is needed."""
         P = self.pack_train_b3()
-        self._packed = self._packed_b3 = None  # running statistics are about to change
+        self._packed = self._packed_b3 = self._packed_n16 = None  # running statistics are about to change
         n = x.shape[0]
         y0, st = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True)
         s, t = self._finalize(st, y0.numel() // 64, self.input_layer[1])
@@ -490,7 +646,7 @@ class IR50(nn.Module):
         updates its running buffers; Dropout(0.4) before the head FC.  ``head_mask`` ([N,h,w,512],
         pre-scaled) overrides the generated dropout mask (parity tests)."""
         P = self.pack_train()
-        self._packed = self._packed_b3 = None  # running statistics are about to change: folded eval weights go stale
+        self._packed = self._packed_b3 = self._packed_n16 = None  # running statistics are about to change: folded eval weights go stale
         n = x.shape[0]
         y0, st = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True)
         s, t = self._finalize(st, y0.numel() // 64, self.input_layer[1])
@@ -544,15 +700,20 @@ class IR50(nn.Module):
         train(): ``bn_mode == "reference"`` reproduces the reference, whose model.train() also puts
         this frozen encoder's BatchNorm/Dropout layers in train mode (SURVEY.md F6);
         ``bn_mode == "frozen"`` keeps the encoder in eval behaviour (common practice, faster)."""
-        if self.precision not in ("bf16x3", "fp32"):
+        if self.precision not in ("bf16x3", "fp32", "bf16", "fp16"):
             raise ValueError(f"unknown precision {self.precision!r}")
+        narrow = self.NARROW.get(self.precision)
         if self.training and self.bn_mode == "reference":
+            if narrow is not None:
+                return self._forward_batch_stats_n16(x, narrow, head_mask)
             if self.precision == "bf16x3":
                 return self._forward_batch_stats_b3(x, head_mask)
             return self._forward_batch_stats(x, head_mask)
         if self._release_plan() is not None:
             raise NotImplementedError("released encoder parameters need model.train() with bn_mode = 'reference' (what the "
                                       "reference's gradual release runs in); use torch.no_grad() for evaluation")
+        if narrow is not None:
+            return self._forward_n16(x, narrow)
         if self.precision == "bf16x3":
             return self._forward_b3(x)
         P = self.pack()

@@ -38,6 +38,12 @@ enum cer_status {
 
 enum cer_act { CER_ACT_NONE = 0, CER_ACT_PRELU = 1, CER_ACT_LEAKY = 2, CER_ACT_RELU = 3, CER_ACT_GELU = 4 };
 
+/* Storage type of the 16-bit tensors of a launch (cer_conv_desc.storage and the *_n16 entry points):
+ * 0 = none (fp32 tensors / split hi+lo bf16 pairs, as the pointers say); otherwise every 16-bit tensor is ONE plane of
+ * bf16 or IEEE half -- the reference's own GPU recipe is fp16 autocast (trainer.py:14-15,341,367), BASELINE cfg5 asks
+ * for "bf16 storage / fp32 accumulate". */
+enum cer_storage { CER_STORE_NONE = 0, CER_STORE_BF16 = 1, CER_STORE_F16 = 2 };
+
 const char *cer_last_error(void);
 int cer_version(void);
 
@@ -81,11 +87,13 @@ typedef struct cer_conv_desc {
     int32_t tile;         /* 0 = auto; else forces a tile config (testing / tuning) */
     int32_t x_ld, y_ld;   /* pitch in floats between pixels of x / rows of y; 0 = dense (Cin / Cout).
                              Lets a layer read or write a column slice of a wider [rows, ld] buffer. */
+    int32_t storage;      /* cer_storage: narrow (single 16-bit plane) operands / outputs, see cer_conv_io */
 } cer_conv_desc;
 
 int cer_conv_kpad(int KH, int KW, int Cin);
 size_t cer_conv2d_workspace_bytes(const cer_conv_desc *d);
-int cer_conv2d_stats_tiles(const cer_conv_desc *d, int bf16x3);  /* rows of `stats` the launch will write */
+/* rows of `stats` the launch will write; kernel_family: 0 = fp32 kernel, 1 = bf16x3 (split operands), 2 = narrow (n16) */
+int cer_conv2d_stats_tiles(const cer_conv_desc *d, int kernel_family);
 int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const float *w,
                    const float *in_scale, const float *in_shift,
                    const float *bias, const float *alpha,
@@ -102,6 +110,12 @@ int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const float *w,
  * Outputs (any subset): y fp32; (y_hi, y_lo) split; (y2_hi, y2_lo) = split(out*s2[c]+t2[c]), the next
  * layer's eval-mode pre-conv BatchNorm applied by the producer (the zero padding of the consumer
  * then stays exactly zero).  The residual may be fp32 (`residual`) or split (`res_hi`, `res_lo`).
+ *
+ * Narrow mode (desc.storage = CER_STORE_BF16 / CER_STORE_F16): x_hi, w_hi, res_hi, y_hi are single planes of that type
+ * and every *_lo pointer must be NULL; ONE v_mfma_f32_16x16x32_{bf16,f16} per 32-deep product, fp32 accumulate, fp32
+ * epilogue (bias / bias9 / PReLU / residual / batch statistics), one rounding at the store.  This is what the
+ * reference's --amp recipe computes (fp16 autocast) and BASELINE cfg5's "bf16 storage".  With fp32 operands
+ * (x, w given; the Cin = 3 stem) and storage != 0 the fp32 kernel runs and y_hi receives the narrow plane.
  * ---------------------------------------------------------------------- */
 typedef struct cer_conv_io {
     const float *x, *w;                       /* fp32 mode operands */
@@ -122,6 +136,14 @@ int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, void *workspac
 /* The bf16x3 kernel variant cer_conv2d_run launches for this descriptor (desc.tile, or the automatic choice when it is 0):
  * 41/42/44/45 = conv_b3_dma16_kernel<128x128 / 128x64 / 64x128 / 64x64>, see csrc/conv_b3.hip.  0 = invalid. */
 int cer_conv2d_b3_tile(const cer_conv_desc *d);
+/* The narrow kernel variant for this descriptor: 61..67 = conv_n16_kernel tiles (csrc/conv_n16.hip).  0 = invalid. */
+int cer_conv2d_n16_tile(const cer_conv_desc *d);
+
+/* v' = v*scale[c]+shift[c] (channels-last; scale/shift may be NULL) -> one 16-bit plane of `storage` (bf16 / half),
+ * round-to-nearest-even; and back (tests, fp32 consumers). */
+int cer_to_n16(const float *x, const float *scale, const float *shift, int C, uint16_t *out, size_t n, int storage,
+               void *stream);
+int cer_from_n16(const uint16_t *x, float *out, size_t n, int storage, void *stream);
 
 /* v' = v*scale[c]+shift[c] (channels-last, C channels; scale/shift may be NULL) -> (bf16(v'), bf16(v' - bf16(v'))),
  * round-to-nearest-even on both parts. */
@@ -259,6 +281,14 @@ int cer_bn_apply_nhwc_b3(const float *y, const float *scale, const float *shift,
                          const uint16_t *res_hi, const uint16_t *res_lo, const float *res_scale, const float *res_shift,
                          const float *mask, float *out, uint16_t *out_hi, uint16_t *out_lo, float *stats, int N, int Ho,
                          int Wo, int C, int res_stride, int Hr, int Wr, void *stream);
+
+/* The same pass on NARROW tensors (cer_storage: one bf16 / half plane each): the conv result comes as fp32 (`y`) or narrow
+ * (`y16`, exactly one of the two), the residual as fp32 or narrow, the result goes to `out16` and/or fp32 `out`;
+ * arithmetic and statistics are fp32 (taken before the final rounding).  16-byte accesses: C % 8 == 0. */
+int cer_bn_apply_nhwc_n16(const float *y, const uint16_t *y16, const float *scale, const float *shift, const float *alpha,
+                          const float *res, const uint16_t *res16, const float *res_scale, const float *res_shift,
+                          const float *mask, float *out, uint16_t *out16, float *stats, int N, int Ho, int Wo, int C,
+                          int res_stride, int Hr, int Wr, int storage, void *stream);
 
 /* Nesterov SGD over flat buffers (reference instantiators.py:74-92: torch.optim.SGD(momentum .9, nesterov, wd 1e-4);
  * trainer.py:385-391): d = grad + wd*p; buf = first_step ? d : mu*buf + (1-damp)*d; d = nesterov ? d + mu*buf : buf;

@@ -24,10 +24,6 @@ def _ref_conv(x_nchw, w, stride, pad, dil=1):
     (2, 128, 256, 10, 3, 1, 2),
     (2, 128, 256, 10, 3, 1, 4),
     (2, 128, 256, 10, 3, 1, 5),
-    (2, 128, 256, 10, 3, 1, 11),   # double-buffered variants kept for A/B measurements
-    (2, 128, 256, 10, 3, 1, 22),
-    (2, 128, 256, 10, 3, 1, 14),
-    (2, 128, 256, 10, 3, 1, 25),
     (5, 256, 512, 5, 3, 2, 0),
     (4, 64, 128, 9, 1, 2, 0),
     (2, 32, 7, 6, 1, 1, 0),     # Cout not a multiple of 4 (regressor-like)

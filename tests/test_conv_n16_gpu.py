@@ -1,0 +1,195 @@
+"""Narrow (single bf16 / half plane) convolution, one MFMA per product with fp32 accumulation (csrc/conv_n16.hip),
+vs torch-CPU float64 on the SAME rounded operands: the only differences left are the fp32 accumulation order and the
+final rounding of the narrow output, so the bounds are tight and derived, not tuned."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DTYPES = [torch.bfloat16, torch.float16]
+EPS = {torch.bfloat16: 2.0 ** -8, torch.float16: 2.0 ** -11}   # half an ulp, relative
+
+
+def _setup(n, cin, cout, hw, k, seed, dtype):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, cin, hw, hw, generator=g).to(dtype)
+    w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dtype)
+    return x, w
+
+
+def _dev(x_nchw, w_oihw):
+    from feature_vs_text_compound_emotion_amd import ops
+    xd = x_nchw.permute(0, 2, 3, 1).contiguous().cuda()
+    wd = ops.to_n16(ops.pack_conv_weight(w_oihw.float().cuda()), w_oihw.dtype)   # exact: the values are already narrow
+    return xd, wd
+
+
+def test_to_n16_is_round_to_nearest_even_and_from_n16_is_exact():
+    from feature_vs_text_compound_emotion_amd import ops
+    x = torch.randn(4096, generator=torch.Generator().manual_seed(0)) * 37.0
+    s, t = torch.rand(64) + 0.5, torch.randn(64)
+    for dt in DTYPES:
+        y = ops.to_n16(x.cuda(), dt)
+        assert torch.equal(y.cpu(), x.to(dt))
+        assert torch.equal(ops.from_n16(y).cpu(), x.to(dt).float())
+        ya = ops.to_n16(x.view(64, 64).cuda(), dt, scale=s.cuda(), shift=t.cuda())
+        ref = torch.addcmul(t, x.view(64, 64), s)   # fused multiply-add like the kernel's v*s+t contraction, or ...
+        alt = (x.view(64, 64) * s + t)              # ... two roundings
+        got = ya.cpu()
+        assert (torch.eq(got, ref.to(dt)) | torch.eq(got, alt.to(dt))).all()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,cin,cout,hw,k,stride,tile", [
+    (3, 64, 64, 12, 3, 1, 0), (4, 64, 128, 9, 1, 2, 0), (2, 128, 256, 10, 3, 1, 0), (7, 512, 512, 5, 3, 1, 0),
+    # 256x256, 8 waves (two epilogue passes): several small images per tile, ragged M and Cout, stride 2, 1x1
+    (4, 128, 256, 10, 3, 1, 61), (7, 256, 512, 5, 3, 2, 61), (3, 64, 300, 7, 3, 1, 61), (4, 64, 256, 9, 1, 2, 61),
+    (1, 64, 256, 23, 3, 1, 61),
+    # 256x128, 8 waves
+    (4, 128, 128, 10, 3, 1, 62), (5, 64, 128, 9, 3, 2, 62), (3, 128, 100, 7, 3, 1, 62), (2, 256, 128, 13, 1, 1, 62),
+    # 256x64, 4 waves (two blocks per CU)
+    (3, 64, 64, 12, 3, 1, 63), (3, 64, 40, 7, 3, 1, 63), (5, 128, 64, 9, 3, 2, 63), (4, 64, 64, 9, 1, 2, 63),
+    # 128x128 / 128x64 / 64x64 / 64x128
+    (2, 128, 256, 10, 3, 1, 64), (5, 64, 128, 9, 3, 2, 64), (3, 64, 100, 7, 3, 1, 64),
+    (3, 64, 64, 12, 3, 1, 65), (3, 64, 96, 7, 3, 1, 65),
+    (3, 64, 96, 7, 3, 1, 66), (1, 64, 40, 5, 3, 1, 66),
+    (2, 256, 256, 10, 3, 1, 67), (2, 128, 256, 10, 3, 2, 67)])
+def test_conv_n16_matches_float64_on_the_same_operands(n, cin, cout, hw, k, stride, tile, dtype):
+    from feature_vs_text_compound_emotion_amd import ops
+    x, w = _setup(n, cin, cout, hw, k, n * 100 + cin + cout, dtype)
+    ref = F.conv2d(x.double(), w.double(), None, stride, k // 2)
+    mag = F.conv2d(x.double().abs(), w.double().abs(), None, stride, k // 2)
+    xd, wd = _dev(x, w)
+    r = ops.conv2d_n16(xd, wd, k, k, stride=stride, pad=(k // 2, k // 2), tile=tile, out_f32=True, out_n16=True, want_stats=True)
+    got = r["y"].cpu().permute(0, 3, 1, 2).double()
+    # products of two narrow values are exact in fp32; what is left is the fp32 accumulation: K * 2^-24 * sum |x||w|
+    bound = mag * (cin * k * k * 2.0 ** -24) + 1e-9
+    assert ((got - ref).abs() <= bound).all(), ((got - ref).abs() / bound).max().item()
+    # the narrow output is the fp32 result rounded once
+    assert torch.equal(r["n16"].cpu(), r["y"].cpu().to(dtype))
+    st = r["stats"].cpu().double().sum(0)
+    assert (st[0] - ref.sum((0, 2, 3))).abs().max().item() < 1e-2
+    assert (st[1] - (ref * ref).sum((0, 2, 3))).abs().max().item() < 1e-2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile", [0, 61, 62, 64, 67])
+def test_conv_n16_fused_epilogue(tile, dtype):
+    """bias + PReLU + strided narrow residual, fp32 and narrow outputs, statistics of the raw conv."""
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(5)
+    n, cin, cout, hw = 2, 64, 128, 10
+    x, w = _setup(n, cin, cout, hw, 3, 77, dtype)
+    bias, alpha = torch.randn(cout, generator=g), torch.rand(cout, generator=g) * 0.3 + 0.1
+    res = torch.randn(n, cout, hw, hw, generator=g).to(dtype)
+    raw = F.conv2d(x.double(), w.double(), None, 2, 1)
+    z = raw + bias.double().view(1, -1, 1, 1)
+    z = torch.where(z >= 0, z, z * alpha.double().view(1, -1, 1, 1)) + res.double()[:, :, ::2, ::2]
+    xd, wd = _dev(x, w)
+    rd = res.permute(0, 2, 3, 1).contiguous().cuda()
+    r = ops.conv2d_n16(xd, wd, 3, 3, stride=2, pad=(1, 1), bias=bias.cuda(), alpha=alpha.cuda(), act1=ops.ACT_PRELU,
+                       residual=rd, res_stride=2, out_f32=True, want_stats=True, tile=tile)
+    assert (r["y"].cpu().permute(0, 3, 1, 2).double() - z).abs().max().item() < 2e-5
+    assert torch.equal(r["n16"].cpu(), r["y"].cpu().to(dtype))
+    st = r["stats"].cpu().double().sum(0)
+    assert (st[0] - raw.sum((0, 2, 3))).abs().max().item() < 1e-2
+    assert (st[1] - (raw * raw).sum((0, 2, 3))).abs().max().item() < 1e-2
+    # fp32 residual
+    r2 = ops.conv2d_n16(xd, wd, 3, 3, stride=2, pad=(1, 1), bias=bias.cuda(), alpha=alpha.cuda(), act1=ops.ACT_PRELU,
+                        residual=rd.float(), res_stride=2, out_f32=True, out_n16=False, tile=tile)
+    assert torch.equal(r2["y"], r["y"])
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_linear_n16_split_k(dtype):
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(6)
+    m, k, cout = 70, 1280, 512
+    x = torch.randn(m, k, generator=g).to(dtype)
+    w = (torch.randn(cout, k, generator=g) / k ** 0.5).to(dtype)
+    b = torch.randn(cout, generator=g)
+    ref = F.linear(x.double(), w.double(), b.double())
+    for tile in (0, 61, 64, 66, 67):
+        r = ops.conv2d_n16(x.cuda().view(m, 1, 1, k), w.cuda().contiguous(), 1, 1, bias=b.cuda(), split_k=5, out_f32=True,
+                           out_n16=False, tile=tile)
+        assert (r["y"].view(m, cout).cpu().double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,cin,cout,hw,tile", [(2, 64, 64, 9, 0), (3, 64, 128, 6, 62), (2, 128, 256, 5, 61), (1, 64, 100, 12, 65),
+                                                 (1, 64, 64, 37, 63)])
+def test_input_batchnorm_folded_into_the_narrow_conv(n, cin, cout, hw, tile, dtype):
+    """conv3x3(pad0(s*x + t)) == conv3x3'(pad0(x)) + bias9[border case] with w' = w*s rounded to the narrow type."""
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(hw * 7 + cout)
+    x, w = _setup(n, cin, cout, hw, 3, 11 * n + cout, dtype)
+    s1, t1 = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.5
+    alpha = torch.rand(cout, generator=g) * 0.3 + 0.1
+    wp, b9 = ops.fold_input_bn_3x3(w.float().cuda(), s1.cuda(), t1.cuda())
+    wn = ops.to_n16(wp, dtype)
+    # reference on the operands the kernel really sees: narrow x, narrow(w*s), fp32 shift term
+    w_eff = (w.float() * s1.view(1, -1, 1, 1)).to(dtype).double()
+    shift_img = torch.ones(1, cin, hw, hw, dtype=torch.float64) * t1.double().view(1, -1, 1, 1)
+    z = F.conv2d(x.double(), w_eff, None, 1, 1) + F.conv2d(shift_img, w.double(), None, 1, 1)
+    ref = torch.where(z >= 0, z, z * alpha.double().view(1, -1, 1, 1))
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    r = ops.conv2d_n16(xd, wn, 3, 3, pad=(1, 1), alpha=alpha.cuda(), act1=ops.ACT_PRELU, bias9=b9, tile=tile, out_f32=True,
+                       out_n16=False)
+    assert (r["y"].cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item() < 3e-5
+    with pytest.raises(RuntimeError, match="bias9"):
+        ops.conv2d_n16(xd, wn, 3, 3, stride=2, pad=(1, 1), bias9=b9)
+
+
+def test_conv_n16_rejects_what_it_cannot_take():
+    from feature_vs_text_compound_emotion_amd import ops
+    x = torch.zeros(1, 4, 4, 32, dtype=torch.bfloat16).cuda()
+    w = torch.zeros(8, ops.conv_kpad(1, 1, 32), dtype=torch.bfloat16).cuda()
+    with pytest.raises(RuntimeError, match="multiple of 64"):
+        ops.conv2d_n16(x, w, 1, 1)
+    with pytest.raises(ValueError):
+        ops.conv2d_n16(x, w.half(), 1, 1)   # mixed storage types
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_stem_fp32_kernel_with_narrow_output(dtype):
+    """The Cin = 3 stem stays on the fp32 kernel (reads the caller's NCHW frames) and writes the narrow plane directly."""
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x, w = torch.randn(3, 3, 12, 12, generator=g), torch.randn(64, 3, 3, 3, generator=g) * 0.2
+    b, a = torch.randn(64, generator=g), torch.rand(64, generator=g) * 0.3 + 0.1
+    z = F.conv2d(x, w, b, 1, 1)
+    ref = torch.where(z >= 0, z, z * a.view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    r = ops.conv2d(x.cuda(), ops.pack_conv_weight(w.cuda()), 3, 3, pad=(1, 1), bias=b.cuda(), alpha=a.cuda(), act1=ops.ACT_PRELU,
+                   x_nchw=True, out_n16=dtype)
+    assert (r["y"].cpu() - ref).abs().max().item() < 2e-5
+    assert torch.equal(r["n16"].cpu(), r["y"].cpu().to(dtype))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bn_apply_narrow_io(dtype):
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(9)
+    n, h, c = 3, 10, 64
+    z, res = torch.randn(n, 5, 5, c, generator=g), torch.randn(n, h, h, c, generator=g).to(dtype)
+    s, t = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    alpha = torch.rand(c, generator=g) * 0.3 + 0.1
+    rs, rt = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    for zin in (z, z.to(dtype)):   # conv result as fp32 or as a narrow plane
+        zz = zin.double()
+        o = ops.bn_apply_nhwc_n16(zin.cuda(), s.cuda(), t.cuda(), dtype=dtype, res=res.cuda(), res_stride=2, want_stats=True,
+                                  out_f32=True)
+        ref = zz * s.double() + t.double() + res.double()[:, ::2, ::2]
+        assert (o["y"].cpu().double() - ref).abs().max().item() < 1e-5
+        assert torch.equal(o["n16"].cpu(), o["y"].cpu().to(dtype))
+        st = o["stats"].cpu().double().sum(0)
+        assert (st[0] - ref.sum((0, 1, 2))).abs().max().item() < 1e-2
+        assert (st[1] - (ref * ref).sum((0, 1, 2))).abs().max().item() < 1e-2
+    # PReLU + mask + normalised projection shortcut (fp32 residual with its own affine)
+    mask = (torch.rand(n, 5, 5, c, generator=g) > 0.4).float() / 0.6
+    r32 = torch.randn(n, 5, 5, c, generator=g)
+    o = ops.bn_apply_nhwc_n16(z.cuda(), s.cuda(), t.cuda(), dtype=dtype, alpha=alpha.cuda(), res=r32.cuda(), res_scale=rs.cuda(),
+                              res_shift=rt.cuda(), mask=mask.cuda(), out_f32=True, out_n16=False)
+    v = z * s + t
+    ref = torch.where(v >= 0, v, v * alpha) * mask + (r32 * rs + rt)
+    assert (o["y"].cpu() - ref).abs().max().item() < 1e-5
