@@ -1,16 +1,23 @@
 """Training clips/sec of the hot path on N MI355X (one process per GPU, RCCL over xGMI).
 
     python bench.py [--gpus N --steps K --warmup W] [--hw 224|40] [--batch 32] [--length 32]
+                    [--precision bf16x3|fp32|bf16|fp16] [--model LFAN|JMT|MT|CAN] [--n-cls 7]
 
-A step = one optimisation step of the tri-modal LFAN on one resident synthetic batch per
-rank: zero_grad -> IR-50 forward over B*L frames (frozen, fp32 MFMA) -> TCNs -> cross-modal
-fusion -> regressor -> cross-entropy -> backward through the trainable tail -> gradient
-all-reduce (N > 1) -> Nesterov SGD (reference trainer.py:345-391).  Prints ONE JSON line on
-rank 0.  `roofline` is measured live with HIP events around the IR-50 forward (all
-cer::conv_igemm_kernel launches, >99 % of the step's FLOPs); `cpu_baseline` times the CPU
-oracle on a bounded sample of the same workload on this box's host cores (N = 1 only).
+A step = one optimisation step on one resident synthetic batch per rank: zero_grad -> (VGGish + BERT encoders on raw
+audio / token ids) -> frozen IR-50 forward over B*L frames in the reference's model.train() mode -> TCNs -> fusion head ->
+classifier -> cross-entropy -> backward through the trainable tail -> gradient all-reduce (N > 1) -> Nesterov SGD
+(reference trainer.py:345-391).  Prints ONE JSON line on rank 0.
+
+`roofline` is measured live: HIP events on the launch stream around every conv launch of the vision encoder
+(ops.CONV_TRACE), per kernel variant: algorithmic FLOPs / summed durations.  Peak: dense bf16/f16 MFMA 2500 TFLOP/s for the
+narrow kernels (precision bf16 / fp16, one MFMA per product), 2500 / 3 for bf16x3 (three MFMAs per product), 157.3 for fp32.
+At N = 1 the default run adds, inside `roofline.other_configs`, the same workload on the other precisions (fp32 with
+>= 5 timed steps, fp16 and bf16 narrow storage), BASELINE cfg5 (64-frame clips, 8 classes, bf16 storage) and cfg3
+(video + vggish, JMT head: the MFMA attention at 1024 tokens x 6 stacks, with its own roofline), and `cpu_baseline`
+times the CPU oracle on a bounded sample of the same workload on this box's host cores.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -24,12 +31,31 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CUs x 4 SIMD x 64 FLOP/clk x 2.4 GHz
-BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak; the bf16x3 kernels spend 3 MFMAs per product -> 833.3 effective
-MODS = ["video", "vggish", "bert"]
-# kernel variant ids reported by cer_conv2d_b3_tile -> names as rocprofv3 prints them (csrc/conv_b3.hip)
-B3_KERNEL_NAMES = {41: "cer::conv_b3_dma16_kernel<128, 128, 2, 2, 4, 2>", 42: "cer::conv_b3_dma16_kernel<128, 64, 2, 2, 4, 2>",
-                   44: "cer::conv_b3_dma16_kernel<64, 128, 1, 4, 4, 2>", 45: "cer::conv_b3_dma16_kernel<64, 64, 2, 2, 4, 2>",
-                   46: "cer::conv_b3_dma16_kernel<256, 256, 2, 4, 8, 2>", 48: "cer::conv_b3_dma16_kernel<256, 64, 4, 1, 4, 2>"}
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 / f16 MFMA peak (same rate); bf16x3 spends 3 MFMAs per product -> 833.3 effective
+ALL_MODS = ["video", "vggish", "bert"]
+NARROW = ("bf16", "fp16")
+# kernel variant ids reported by cer_conv2d_b3_tile / cer_conv2d_n16_tile -> names as rocprofv3 prints them
+KERNEL_NAMES = {41: "cer::conv_b3_dma16_kernel<128, 128, 2, 2, 4, 2>", 42: "cer::conv_b3_dma16_kernel<128, 64, 2, 2, 4, 2>",
+                44: "cer::conv_b3_dma16_kernel<64, 128, 1, 4, 4, 2>", 45: "cer::conv_b3_dma16_kernel<64, 64, 2, 2, 4, 2>",
+                48: "cer::conv_b3_dma16_kernel<256, 64, 4, 1, 4, 2>",
+                61: "cer::conv_n16_kernel<256, 256, 2, 4, {f16}>", 62: "cer::conv_n16_kernel<256, 128, 4, 2, {f16}>",
+                63: "cer::conv_n16_kernel<256, 64, 4, 1, {f16}>", 64: "cer::conv_n16_kernel<128, 128, 2, 2, {f16}>",
+                65: "cer::conv_n16_kernel<128, 64, 2, 2, {f16}>", 66: "cer::conv_n16_kernel<64, 64, 2, 2, {f16}>",
+                67: "cer::conv_n16_kernel<64, 128, 1, 4, {f16}>"}
+
+
+def peak_tflops(precision):
+    if precision == "fp32":
+        return FP32_MFMA_PEAK_TFLOPS, "fp32 MFMA peak (v_mfma_f32_32x32x2_f32)"
+    if precision == "bf16x3":
+        return BF16_MFMA_PEAK_TFLOPS / 3.0, "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product (bf16x3)"
+    return BF16_MFMA_PEAK_TFLOPS, "dense bf16 / f16 MFMA peak, one MFMA per product (narrow storage)"
+
+
+def dtype_string(precision):
+    return {"bf16x3": "bf16x3 (split hi/lo bf16 operands, 3 MFMAs per product, fp32 accumulate; <= 2^-15 relative per product)",
+            "fp32": "f32", "bf16": "bf16 (one 16-bit plane per tensor, one MFMA per product, fp32 accumulate and epilogue)",
+            "fp16": "f16 (one 16-bit plane per tensor, one MFMA per product, fp32 accumulate and epilogue)"}[precision]
 
 
 def ir50_forward_flops(hw):
@@ -48,28 +74,28 @@ def ir50_forward_flops(hw):
     return 2.0 * macs
 
 
-def build_model(hw, length, device):
-    from feature_vs_text_compound_emotion_amd import synth
-    from feature_vs_text_compound_emotion_amd.lfan import LFAN
-    sd = synth.lfan_state_dict(MODS, n_cls=7, head_hw=hw // 8, seed=0)
-    model = LFAN(backbone_settings={}, output_dim=7, task="CLASSIFICATION", modality=MODS, example_length=length,
-                 kernel_size=5, tcn_channel=synth.TCN_CHANNELS, root_dir="", device=device, head_hw=hw // 8)
-    model.init(load_backbone=False)
-    model.load_state_dict(sd, strict=True)
-    return model.to(device), sd
+def kernel_source_sha():
+    """Identity of the code the traffic profiles were taken on: the conv / BatchNorm kernel sources."""
+    h = hashlib.sha256()
+    csrc = os.path.join(ROOT, "feature_vs_text_compound_emotion_amd", "csrc")
+    for f in ("conv_common.h", "conv_b3.hip", "conv_n16.hip", "conv_igemm.hip", "encoder_bn.hip"):
+        with open(os.path.join(csrc, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
-def measured_traffic(hw, batch, length, encoders, precision, kernel=None):
-    """HBM bytes per step of cer::conv_igemm_kernel from the committed rocprofv3 PMC passes
-    (tools/collect_traffic.py: FETCH_SIZE x2 + WRITE_SIZE, separate passes, gfx950 corrections).  PMC
-    counters cannot be read from inside the timed process, so the value is looked up by configuration
-    and is null when no profile of this exact configuration has been committed."""
-    path = os.path.join(ROOT, "profiles", f"round1b_traffic_{precision}_hw{hw}.json")
+def measured_traffic(cfg, kernel=None):
+    """HBM bytes per launch (or per step over all conv launches) from the committed rocprofv3 PMC passes
+    (tools/collect_traffic.py: FETCH_SIZE x2 + WRITE_SIZE, separate passes, gfx950 corrections).  PMC counters cannot be read
+    from inside the timed process, so the value is looked up -- by configuration AND by the hash of the kernel sources the
+    profile was taken on: a profile of other code is not reported (null)."""
+    path = os.path.join(ROOT, "profiles", f"round2_traffic_{cfg['precision']}_hw{cfg['hw']}_L{cfg['length']}.json")
     try:
         t = json.load(open(path))
     except (OSError, ValueError):
         return None
-    if (str(t.get("batch")), str(t.get("length")), t.get("encoders")) != (str(batch), str(length), encoders):
+    if (str(t.get("batch")), str(t.get("length")), t.get("encoders"), t.get("kernel_source_sha")) != \
+            (str(cfg["batch"]), str(cfg["length"]), cfg["encoders"], kernel_source_sha()):
         return None
     if kernel is not None:  # per launch of one kernel variant, like roofline.achieved
         return t.get("per_kernel", {}).get(kernel, {}).get("hbm_bytes_per_launch")
@@ -91,33 +117,18 @@ def host_threads():
     return n
 
 
-def build_extractor(batch, rank, dev):
-    """VGGish + BERT with seeded weights and one resident raw batch: 1 s of 16 kHz PCM and a 64-slot
-    sentence (63 tokens + 1 pad: the reference's exclude_padding rejects a sentence with no pad)."""
-    from feature_vs_text_compound_emotion_amd import synth
-    from feature_vs_text_compound_emotion_amd.audio_backbone import AudioBackbone
-    from feature_vs_text_compound_emotion_amd.feature_extractor import MultimodalFeatureExtractor
-    from feature_vs_text_compound_emotion_amd.text_encoder import BertEncoderHIP
-    ab, te = AudioBackbone(), BertEncoderHIP()
-    ab.backbone.load_state_dict(synth.make_state_dict(synth.vggish_spec(""), seed=21), strict=True)
-    te.load_state_dict(synth.make_state_dict(synth.bert_spec(""), seed=31), strict=True)
-    fx = MultimodalFeatureExtractor(ab, te, fps=32).to(dev).eval()
-    pcm = torch.stack([synth.make_audio_int16(1.0, 16000, seed=5000 + rank * 1000 + i) for i in range(batch)])
-    ids, mask = synth.make_token_ids(batch, 64, seed=900 + rank, pad_from=[63] * batch)
-    return fx, {"pcm": pcm.to(dev), "ids": ids.to(dev), "mask": mask.to(dev), "mask_cpu": mask}
-
-
 def cpu_baseline(hw, length, encoders=True):
     """CPU oracle, same step, bounded sample (about 10-30 s)."""
     from feature_vs_text_compound_emotion_amd import synth
     from oracle.lfan import cross_entropy_mean, lfan_forward, sgd_nesterov_step
+    MODS = ALL_MODS
     threads = host_threads()
     torch.set_num_threads(threads)
     sd = synth.lfan_state_dict(MODS, n_cls=7, head_hw=hw // 8, seed=0)
     alias = synth.lfan_spec(MODS, head_hw=hw // 8)[1]
     names = [k for k in sd if not k.startswith("spatial.") and k not in alias
              and not k.endswith(("running_mean", "running_var", "num_batches_tracked"))]
-    clips, steps = (8, 3) if hw <= 64 else (1, 1)  # ~10-15 s of CPU work either way
+    clips, steps = (8, 3) if hw <= 64 else (1, 2)  # ~10-30 s of CPU work either way
 
     if encoders:
         import oracle
@@ -167,6 +178,245 @@ def cpu_baseline(hw, length, encoders=True):
                       f"{threads} threads), {dt:.1f} s"}
 
 
+class Workload:
+    """One model + one resident synthetic batch per rank + the optimisation step around it."""
+
+    def __init__(self, cfg, rank, world, dev):
+        from feature_vs_text_compound_emotion_amd import synth
+        from feature_vs_text_compound_emotion_amd.data_parallel import ClipDataParallel, FlatNesterovSGD
+        self.cfg, self.world, self.dev = cfg, world, dev
+        mods, hw, length, n_cls = cfg["modalities"], cfg["hw"], cfg["length"], cfg["n_cls"]
+        name = cfg["model"]
+        if name == "LFAN":
+            from feature_vs_text_compound_emotion_amd.lfan import LFAN
+            sd = synth.lfan_state_dict(mods, n_cls=n_cls, head_hw=hw // 8, seed=0)
+            model = LFAN(backbone_settings={}, output_dim=n_cls, task="CLASSIFICATION", modality=mods, example_length=length,
+                         kernel_size=5, tcn_channel=synth.TCN_CHANNELS, root_dir="", device=dev, head_hw=hw // 8)
+            model.init(load_backbone=False)
+        else:
+            from feature_vs_text_compound_emotion_amd.fusion_heads import CAN, JMT
+            spec, alias = synth.can_spec(mods, n_cls, hw // 8) if name == "CAN" else synth.jmt_spec(mods, name, n_cls, hw // 8)
+            sd = synth.make_state_dict(spec, alias, seed=0)
+            kw = dict(task="CLASSIFICATION", modalities=mods, tcn_settings=synth.TCN_SETTINGS, backbone_settings={},
+                      output_dim=n_cls, root_dir="", device=dev, head_hw=hw // 8, load_backbone=False)
+            model = CAN(**kw) if name == "CAN" else JMT(model_name=name, **kw)
+        model.load_state_dict(sd, strict=True)
+        del sd
+        self.model = model.to(dev)
+        self.model.spatial["visual"].backbone.precision = cfg["precision"]
+        self.model.train()
+        if cfg["release"]:
+            from feature_vs_text_compound_emotion_amd.parameter_control import ResnetParamControl
+            pc = ResnetParamControl(trainer=None, release_count=cfg["release"])
+            for _ in range(cfg["release"]):
+                pc.release_param(self.model.spatial)
+        self.ddp = ClipDataParallel(self.model, world_size=world)
+        # the reference's torch.optim.SGD(momentum .9, nesterov, wd 1e-4, lr 1e-3 -- F8) as one fused launch over flat buffers
+        self.opt = FlatNesterovSGD(self.ddp, lr=1e-3, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=True)
+        x, labels = synth.make_clip_batch(mods, cfg["batch"], length, hw=hw, seed=1234 + rank, n_cls=n_cls)
+        self.x = {k: v.to(dev) for k, v in x.items()}
+        self.labels = labels.to(dev)
+        self.fx = self.raw = None
+        if cfg["encoders"] == "on":
+            self._build_extractor(rank)
+        self.ev = []
+        vis = self.model.spatial["visual"]
+        self._hooks = [vis.register_forward_pre_hook(self._pre), vis.register_forward_hook(self._post)]
+
+    def _build_extractor(self, rank):
+        """VGGish + BERT with seeded weights and one resident raw batch: L/32 s of 16 kHz PCM (one 0.96 s example per
+        video frame at 32 fps) and a 64-slot sentence (63 tokens + 1 pad: the reference's exclude_padding rejects a sentence
+        with no pad)."""
+        from feature_vs_text_compound_emotion_amd import synth
+        from feature_vs_text_compound_emotion_amd.audio_backbone import AudioBackbone
+        from feature_vs_text_compound_emotion_amd.feature_extractor import MultimodalFeatureExtractor
+        from feature_vs_text_compound_emotion_amd.text_encoder import BertEncoderHIP
+        cfg, dev = self.cfg, self.dev
+        ab = AudioBackbone()
+        ab.backbone.load_state_dict(synth.make_state_dict(synth.vggish_spec(""), seed=21), strict=True)
+        te = None
+        if "bert" in cfg["modalities"]:
+            te = BertEncoderHIP()
+            te.load_state_dict(synth.make_state_dict(synth.bert_spec(""), seed=31), strict=True)
+        self.fx = MultimodalFeatureExtractor(ab, te if te is not None else torch.nn.Identity(), fps=32).to(dev).eval()
+        secs = cfg["length"] / 32.0
+        pcm = torch.stack([synth.make_audio_int16(secs, 16000, seed=5000 + rank * 1000 + i) for i in range(cfg["batch"])])
+        self.raw = {"pcm": pcm.to(dev)}
+        if te is not None:
+            ids, mask = synth.make_token_ids(cfg["batch"], 64, seed=900 + rank, pad_from=[63] * cfg["batch"])
+            self.raw.update(ids=ids.to(dev), mask=mask.to(dev), mask_cpu=mask)
+
+    def _pre(self, mod, inp):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.ev.append([e, None])
+
+    def _post(self, mod, inp, out):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        self.ev[-1][1] = e
+
+    def inputs(self):
+        if self.fx is None:
+            return self.x
+        length = self.cfg["length"]
+        out = {}
+        for m in self.cfg["modalities"]:  # raw audio + token ids -> per-frame features on the GPU (frozen encoders)
+            if m == "video":
+                out[m] = self.x["video"]
+            elif m == "vggish":
+                out[m] = self.fx.audio_features(self.raw["pcm"], length)
+            else:
+                out[m] = self.fx.text_features(self.raw["ids"], self.raw["mask"], length, self.raw["mask_cpu"])
+        return out
+
+    def step(self):
+        from feature_vs_text_compound_emotion_amd.lfan import cross_entropy_loss
+        self.ddp.zero_grad()
+        out = self.model(self.inputs())
+        loss = cross_entropy_loss(out, self.labels)
+        loss.backward()
+        self.ddp.all_reduce_gradients()
+        self.opt.step()
+        return loss
+
+    def fence(self):
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def measure(self, steps, warmup):
+        """W untimed + exactly K timed steps (barrier + synchronize on both sides, max over ranks) -> result dict."""
+        from feature_vs_text_compound_emotion_amd import ops
+        cfg = self.cfg
+        for _ in range(warmup):
+            self.step()
+        self.ev.clear()
+        trace = ops.CONV_TRACE = [] if cfg["precision"] != "fp32" else None  # HIP events around every encoder conv launch
+        atrace = ops.ATTN_TRACE = [] if cfg["model"] in ("JMT", "MT") else None
+        self.fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = self.step()
+        self.fence()
+        dt = time.perf_counter() - t0
+        ops.CONV_TRACE = ops.ATTN_TRACE = None
+        if self.world > 1:
+            t = torch.tensor([dt], device=self.dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = t.item()
+        enc_ms = sum(s.elapsed_time(e) for s, e in self.ev) / max(len(self.ev), 1)
+        frames = cfg["batch"] * cfg["length"]
+        flops = ir50_forward_flops(cfg["hw"]) * frames
+        achieved = flops / (enc_ms * 1e-3) / 1e12
+        peak, peak_note = peak_tflops(cfg["precision"])
+        # per kernel variant: algorithmic FLOPs of its launches / their HIP-event durations (launch stream), over the timed steps
+        kernels = {}
+        f16 = "true" if cfg["precision"] == "fp16" else "false"
+        for tile, fl, e0, e1, nbytes in (trace or []):
+            k = kernels.setdefault(KERNEL_NAMES.get(tile, f"conv tile {tile}").replace("{f16}", f16),
+                                   {"launches": 0, "flops": 0.0, "ms": 0.0, "algo_bytes": 0.0})
+            k["launches"] += 1
+            k["flops"] += fl
+            k["algo_bytes"] += nbytes
+            k["ms"] += e0.elapsed_time(e1)
+        for k in kernels.values():
+            k["launches_per_step"] = k["launches"] / steps
+            k["avg_launch_ms"] = k["ms"] / k["launches"]
+            k["flops_per_launch"] = k["flops"] / k["launches"]
+            k["achieved_tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12
+            k["frac"] = k["achieved_tflops"] / peak
+            k["algorithmic_bytes_per_launch"] = k["algo_bytes"] / k["launches"]
+            k["algorithmic_gbps"] = k["algo_bytes"] / (k["ms"] * 1e-3) / 1e9
+            k["ms_per_step"] = k.pop("ms") / steps
+            del k["flops"], k["algo_bytes"]
+        dominant = max(kernels, key=lambda n: kernels[n]["ms_per_step"]) if kernels else None
+        what = {"fp32": "whole IR-50 forward on cer::conv_igemm_kernel (v_mfma_f32_32x32x2_f32)",
+                "bf16x3": "whole IR-50 forward (51 bf16x3 implicit-GEMM convs + head FC, fp32 stem, batch-statistics BatchNorm passes)",
+                }.get(cfg["precision"], "whole IR-50 forward (51 narrow implicit-GEMM convs + head FC, fp32 stem, batch-statistics "
+                                        "BatchNorm passes)")
+        span = {"what": what + ": algorithmic IR-50 FLOPs of the step / HIP-event span of the encoder forward",
+                "achieved": achieved, "frac": achieved / peak, "ms_per_step_in_kernel": enc_ms, "algorithmic_flops_per_step": flops}
+        if dominant is not None:
+            kd = kernels[dominant]
+            roofline = {"bound": "mfma", "kernel": dominant, "achieved": kd["achieved_tflops"], "peak": peak, "unit": "TFLOP/s",
+                        "frac": kd["frac"], "peak_note": peak_note,
+                        "avg_launch_ms": kd["avg_launch_ms"], "launches_per_step": kd["launches_per_step"],
+                        "algorithmic_flops_per_launch": kd["flops_per_launch"],
+                        "definition": "algorithmic FLOPs (2*M*Cout*Cin*KH*KW) of this kernel's launches / their summed HIP-event "
+                                      "durations on the launch stream over the timed steps",
+                        "traffic": measured_traffic(cfg, dominant),
+                        "traffic_note": "HBM bytes per launch of this kernel (rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes, "
+                                        "FETCH x2 per the gfx950 correction, profiles/round2_traffic_*.json, keyed by configuration "
+                                        "and kernel-source hash); algorithmic bytes per launch = input + output tensors + weights "
+                                        "(+ residual)",
+                        "algorithmic_bytes_per_launch": kd["algorithmic_bytes_per_launch"],
+                        "traffic_per_step_all_convs": measured_traffic(cfg),
+                        "kernel_source_sha": kernel_source_sha(),
+                        "all_kernels": kernels, "encoder_span": span}
+        else:
+            roofline = {"bound": "mfma", "kernel": "cer::conv_igemm_kernel (IR-50 forward: 52 implicit-GEMM convs + head FC, "
+                                                   "v_mfma_f32_32x32x2_f32)", "achieved": achieved, "peak": peak,
+                        "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": peak_note, "traffic": None,
+                        "algorithmic_flops_per_step": flops, "ms_per_step_in_kernel": enc_ms}
+        if atrace:
+            att = {}
+            for kind, fl, e0, e1 in atrace:
+                a = att.setdefault(kind, {"launches": 0, "flops": 0.0, "ms": 0.0})
+                a["launches"] += 1
+                a["flops"] += fl
+                a["ms"] += e0.elapsed_time(e1)
+            for kind, a in att.items():
+                a["kernel"] = f"cer::attention_{kind}_kernel<128> (exact fp32 MFMA, flash style)"
+                a["achieved"] = a["flops"] / (a["ms"] * 1e-3) / 1e12
+                a["peak"], a["unit"], a["bound"] = FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", "mfma"
+                a["frac"] = a["achieved"] / FP32_MFMA_PEAK_TFLOPS
+                a["launches_per_step"] = a["launches"] / steps
+                a["ms_per_step"] = a.pop("ms") / steps
+                a["algorithmic_flops_per_step"] = a.pop("flops") / steps
+            att["definition"] = ("algorithmic FLOPs: forward 4*Sq*Sk*D, backward 8*Sq*Sk*D (dV, dP, dQ, dK; the recomputed "
+                                 "S = QK^T is not counted) per (batch, head), / HIP-event durations of the launches")
+            roofline["attention"] = att
+        mods = cfg["modalities"]
+        enc_txt = ("VGGish (log-mel of the clip's PCM, one 0.96 s example per frame)" +
+                   (" and BERT-base (64-token sentence)" if "bert" in mods else "") + " run on the GPU inside the step") \
+            if cfg["encoders"] == "on" else "vggish/bert as pre-computed per-frame features (as the reference trainer feeds them)"
+        return {
+            "value": self.world * cfg["batch"] * steps / dt, "unit": "clips/s", "steps": steps, "warmup": warmup,
+            "ms_per_step": dt / steps * 1e3, "dtype": dtype_string(cfg["precision"]),
+            "config": {"workload": f"{cfg['model']} {'+'.join(mods)} training step: frozen IR-50 forward on {cfg['batch']}x{cfg['length']} "
+                                   f"frames of {cfg['hw']}x{cfg['hw']} + TCN/fusion/classifier forward+backward + CE + fused Nesterov "
+                                   f"SGD; " + enc_txt,
+                       "model": cfg["model"], "modalities": mods, "encoders_on_gpu": cfg["encoders"] == "on",
+                       "clips_per_gpu": cfg["batch"], "global_batch": cfg["batch"] * self.world, "frames_per_clip": cfg["length"],
+                       "frame_hw": cfg["hw"], "n_classes": cfg["n_cls"], "released_encoder_groups": cfg["release"],
+                       "trainable_parameters": int(sum(p.numel() for p in self.ddp.params)), "conv_precision": cfg["precision"],
+                       "parallelism": f"dp{self.world} over clips, flat-bucket RCCL all-reduce", "loss": float(loss.item())},
+            "roofline": roofline}
+
+    def close(self):
+        for h in self._hooks:
+            h.remove()
+
+
+def compact(res):
+    """A secondary measurement as it is nested under roofline.other_configs: the headline figures without the per-kernel list."""
+    r = res["roofline"]
+    out = {"value": res["value"], "unit": res["unit"], "ms_per_step": res["ms_per_step"], "steps": res["steps"],
+           "warmup": res["warmup"], "dtype": res["dtype"], "config": res["config"],
+           "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "peak_note", "avg_launch_ms",
+                                          "launches_per_step", "algorithmic_bytes_per_launch") if k in r}}
+    if "encoder_span" in r:
+        out["roofline"]["encoder_span"] = {k: r["encoder_span"][k] for k in ("achieved", "frac", "ms_per_step_in_kernel")}
+    if "all_kernels" in r:
+        out["roofline"]["all_kernels"] = {n: {"frac": k["frac"], "achieved_tflops": k["achieved_tflops"], "ms_per_step": k["ms_per_step"],
+                                              "launches_per_step": k["launches_per_step"]} for n, k in r["all_kernels"].items()}
+    if "attention" in r:
+        out["roofline"]["attention"] = r["attention"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,22 +425,24 @@ def main():
     ap.add_argument("--hw", type=int, default=224, help="frame size: 224 (north-star shape) or 40 (reference crop)")
     ap.add_argument("--batch", type=int, default=32, help="clips per GPU")
     ap.add_argument("--length", type=int, default=32)
+    ap.add_argument("--n-cls", type=int, default=7, help="7 (MELD, C-EXPR-DB) or 8 (C-EXPR-DB with use_other_class)")
+    ap.add_argument("--model", choices=["LFAN", "JMT", "MT", "CAN"], default="LFAN")
+    ap.add_argument("--modalities", default=None, help="comma list; default video,vggish,bert (LFAN) / video,vggish (JMT, MT, CAN)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra 3 steps on the fp32 kernels (N = 1 only)")
-    ap.add_argument("--precision", choices=["bf16x3", "fp32"], default="bf16x3",
-                    help="IR-50 conv kernels: bf16x3 = split hi/lo bf16 operands, 3 bf16 MFMAs per product, fp32-class "
-                         "accuracy (logit error ~1e-6); fp32 = exact fp32 MFMA")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra configurations (other precisions, cfg5, cfg3; N = 1 only)")
+    ap.add_argument("--precision", choices=["bf16x3", "fp32", "bf16", "fp16"], default="bf16x3",
+                    help="IR-50 conv kernels: bf16x3 = split hi/lo bf16 operands, 3 bf16 MFMAs per product (logit error ~1e-6); "
+                         "fp32 = exact fp32 MFMA; bf16 / fp16 = narrow storage, one MFMA per product, fp32 accumulate (what the "
+                         "reference's --amp recipe computes; BASELINE cfg5)")
     ap.add_argument("--release", type=int, default=0, choices=[0, 1, 2, 3],
                     help="gradual-release groups of the reference's ResnetParamControl to un-freeze before timing "
                          "(0 = as the reference trains: encoder frozen; 1 = output layer; 2 = + stage 4; 3 = + half of stage 3)")
     ap.add_argument("--encoders", choices=["on", "off"], default="on",
-                    help="on: VGGish (log-mel from 1 s PCM) and BERT (64 tokens) run on the GPU inside the step; "
+                    help="on: VGGish (log-mel from PCM) and BERT (64 tokens) run on the GPU inside the step; "
                          "off: pre-computed per-frame features, as the reference trainer feeds them")
     a = ap.parse_args()
 
-    from feature_vs_text_compound_emotion_amd import ops, synth
-    from feature_vs_text_compound_emotion_amd.data_parallel import ClipDataParallel, FlatNesterovSGD, init_process_group_from_env
-    from feature_vs_text_compound_emotion_amd.lfan import cross_entropy_loss
+    from feature_vs_text_compound_emotion_amd.data_parallel import init_process_group_from_env
 
     # CER_BENCH_BACKEND=gloo rehearses the N>1 path on a one-GPU box (all ranks share cuda:0); the driver's
     # real multi-GPU runs use the default: RCCL ("nccl"), one rank per GPU
@@ -204,174 +456,44 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    model, _ = build_model(a.hw, a.length, dev)
-    model.spatial["visual"].backbone.precision = a.precision
-    model.train()
-    if a.release:
-        from feature_vs_text_compound_emotion_amd.parameter_control import ResnetParamControl
-        pc = ResnetParamControl(trainer=None, release_count=a.release)
-        for _ in range(a.release):
-            pc.release_param(model.spatial)
-    ddp = ClipDataParallel(model, world_size=world)
-    # the reference's torch.optim.SGD(momentum .9, nesterov, wd 1e-4, lr 1e-3 -- F8) as one fused launch over flat buffers
-    opt = FlatNesterovSGD(ddp, lr=1e-3, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=True)
-    x, labels = synth.make_clip_batch(MODS, a.batch, a.length, hw=a.hw, seed=1234 + rank)
-    x = {k: v.to(dev) for k, v in x.items()}
-    labels = labels.to(dev)
-    fx = None
-    if a.encoders == "on":
-        fx, raw = build_extractor(a.batch, rank, dev)
+    mods = a.modalities.split(",") if a.modalities else (ALL_MODS if a.model == "LFAN" else ["video", "vggish"])
+    cfg = {"model": a.model, "modalities": mods, "hw": a.hw, "batch": a.batch, "length": a.length, "n_cls": a.n_cls,
+           "precision": a.precision, "release": a.release, "encoders": a.encoders}
+    wl = Workload(cfg, rank, world, dev)
+    res = wl.measure(a.steps, a.warmup)
+    wl.close()
+    del wl
+    torch.cuda.empty_cache()
 
-    ev = []
+    others = {}
+    if world == 1 and not a.no_alt and a.model == "LFAN" and a.release == 0:
+        def leg(name, steps=5, warmup=1, **over):
+            c = dict(cfg)
+            c.update(over)
+            w = Workload(c, rank, world, dev)
+            others[name] = compact(w.measure(steps, warmup))
+            w.close()
+            del w
+            torch.cuda.empty_cache()
+        for prec in ("fp32", "fp16", "bf16"):
+            if prec != a.precision:
+                leg(f"same workload, conv_precision {prec}", precision=prec)
+        # BASELINE cfg5: tri-modal C-EXPR-DB config, 64-frame clips, 8 classes (7 + Other), bf16 storage
+        leg("cfg5: tri-modal, 64-frame clips, 8 classes, bf16 storage", steps=5, warmup=1, precision="bf16", length=64, n_cls=8)
+        # BASELINE cfg3: vision + VGGish, transformer (JMT) head whose final attention runs over L*B = 1024 tokens x 6 stacks
+        leg("cfg3: video+vggish, JMT head (MFMA attention over 1024 tokens)", steps=5, warmup=1, model="JMT",
+            modalities=["video", "vggish"])
 
-    def pre(mod, inp):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        ev.append([e, None])
-
-    def post(mod, inp, out):
-        e = torch.cuda.Event(enable_timing=True)
-        e.record()
-        ev[-1][1] = e
-
-    model.spatial["visual"].register_forward_pre_hook(pre)
-    model.spatial["visual"].register_forward_hook(post)
-
-    def step():
-        ddp.zero_grad()
-        inputs = x
-        if fx is not None:  # raw audio + token ids -> per-frame features on the GPU (frozen encoders)
-            inputs = fx(x["video"], raw["pcm"], raw["ids"], raw["mask"], raw["mask_cpu"])
-        out = model(inputs)
-        loss = cross_entropy_loss(out, labels)
-        loss.backward()
-        ddp.all_reduce_gradients()
-        opt.step()
-        return loss
-
-    def fence():
-        torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(a.warmup):
-        step()
-    ev.clear()
-    trace = ops.CONV_TRACE = [] if a.precision == "bf16x3" else None  # HIP events around every bf16x3 conv launch
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step()
-    fence()
-    dt = time.perf_counter() - t0
-    ops.CONV_TRACE = None
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = t.item()
-    enc_ms = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
-    frames = a.batch * a.length
-    flops = ir50_forward_flops(a.hw) * frames
-    achieved = flops / (enc_ms * 1e-3) / 1e12
-    b3 = a.precision == "bf16x3"
-    peak = BF16_MFMA_PEAK_TFLOPS / 3.0 if b3 else FP32_MFMA_PEAK_TFLOPS
-
-    # per kernel variant: algorithmic FLOPs of its launches / their HIP-event durations (launch stream), over the timed steps
-    kernels = {}
-    for tile, fl, e0, e1, nbytes in (trace or []):
-        k = kernels.setdefault(B3_KERNEL_NAMES.get(tile, f"conv_b3 tile {tile}"),
-                               {"launches": 0, "flops": 0.0, "ms": 0.0, "algo_bytes": 0.0})
-        k["launches"] += 1
-        k["flops"] += fl
-        k["algo_bytes"] += nbytes
-        k["ms"] += e0.elapsed_time(e1)
-    for k in kernels.values():
-        k["launches_per_step"] = k["launches"] / a.steps
-        k["avg_launch_ms"] = k["ms"] / k["launches"]
-        k["flops_per_launch"] = k["flops"] / k["launches"]
-        k["achieved_tflops"] = k["flops"] / (k["ms"] * 1e-3) / 1e12
-        k["frac"] = k["achieved_tflops"] / peak
-        k["ms_per_step"] = k.pop("ms") / a.steps
-        k["algorithmic_bytes_per_launch"] = k["algo_bytes"] / k["launches"]
-        del k["flops"]
-    dominant = max(kernels, key=lambda n: kernels[n]["ms_per_step"]) if kernels else None
-
-    alt = None
-    if world == 1 and b3 and not a.no_alt:
-        # the same step on the exact-fp32 MFMA kernels (2 timed steps): the other point of the
-        # accuracy/throughput trade-off, priced against ITS roofline (fp32 MFMA peak)
-        model.spatial["visual"].backbone.precision = "fp32"
-        step()
-        ev.clear()
-        fence()
-        t1 = time.perf_counter()
-        for _ in range(2):
-            step()
-        fence()
-        dt1 = (time.perf_counter() - t1) / 2
-        ms1 = sum(s.elapsed_time(e) for s, e in ev) / max(len(ev), 1)
-        ach1 = flops / (ms1 * 1e-3) / 1e12
-        alt = {"conv_precision": "fp32", "value": a.batch / dt1, "unit": "clips/s", "ms_per_step": dt1 * 1e3,
-               "roofline": {"bound": "mfma", "kernel": "cer::conv_igemm_kernel (v_mfma_f32_32x32x2_f32)", "achieved": ach1,
-                            "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach1 / FP32_MFMA_PEAK_TFLOPS,
-                            "ms_per_step_in_kernel": ms1}}
-        model.spatial["visual"].backbone.precision = a.precision
-    span = {"what": ("whole IR-50 forward (51 bf16x3 implicit-GEMM convs + head FC, fp32 stem, batch-statistics BatchNorm "
-                     "passes): algorithmic IR-50 FLOPs of the step / HIP-event span of the encoder forward" if b3 else
-                     "whole IR-50 forward on cer::conv_igemm_kernel (v_mfma_f32_32x32x2_f32)"),
-            "achieved": achieved, "frac": achieved / peak, "ms_per_step_in_kernel": enc_ms, "algorithmic_flops_per_step": flops}
-    traffic_note = ("HBM bytes per step over all conv kernel launches (rocprofv3 PMC passes, profiles/*traffic*_hw*.json: "
-                    "FETCH_SIZE x2 + WRITE_SIZE; the x2 read correction is calibrated for 128-B requests and may over-count "
-                    "64-B row segments); algorithmic minimum 18.6 MB/frame @40x40, 584 MB/frame @224x224 (SURVEY 8d)")
-    if dominant is not None:
-        kd = kernels[dominant]
-        roofline = {"bound": "mfma", "kernel": dominant, "achieved": kd["achieved_tflops"], "peak": peak, "unit": "TFLOP/s",
-                    "frac": kd["frac"], "peak_note": "dense bf16 MFMA peak 2500 TFLOP/s / 3 MFMAs per product (bf16x3)",
-                    "avg_launch_ms": kd["avg_launch_ms"], "launches_per_step": kd["launches_per_step"],
-                    "algorithmic_flops_per_launch": kd["flops_per_launch"],
-                    "definition": "algorithmic FLOPs (2*M*Cout*Cin*KH*KW) of this kernel's launches / their summed HIP-event "
-                                  "durations on the launch stream over the timed steps",
-                    "traffic": measured_traffic(a.hw, a.batch, a.length, a.encoders, a.precision, dominant),
-                    "traffic_note": "HBM bytes per launch of this kernel (rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes, "
-                                    "FETCH x2 per the gfx950 correction, profiles/round1b_traffic_*.json); algorithmic bytes per "
-                                    "launch = split input + output tensors + weights",
-                    "algorithmic_bytes_per_launch": kd["algo_bytes"] / kd["launches"],
-                    "traffic_per_step_all_convs": measured_traffic(a.hw, a.batch, a.length, a.encoders, a.precision),
-                    "all_kernels": kernels, "encoder_span": span}
-    else:
-        roofline = {"bound": "mfma", "kernel": "cer::conv_igemm_kernel (IR-50 forward: 52 implicit-GEMM convs + head FC, "
-                                               "v_mfma_f32_32x32x2_f32)", "achieved": achieved, "peak": peak,
-                    "unit": "TFLOP/s", "frac": achieved / peak, "peak_note": "fp32 MFMA peak",
-                    "traffic": measured_traffic(a.hw, a.batch, a.length, a.encoders, a.precision), "traffic_note": traffic_note,
-                    "algorithmic_flops_per_step": flops, "ms_per_step_in_kernel": enc_ms}
     if rank == 0:
-        res = {
-            "metric": "training clips/sec (32-frame tri-modal clip)",
-            "value": world * a.batch * a.steps / dt,
-            "unit": "clips/s",
-            "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": dt / a.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "bf16x3 (split hi/lo bf16 operands, fp32 accumulate; fp32-class accuracy)" if b3 else "f32",
-            "data": "synthetic",
-            "config": {"workload": f"LFAN tri-modal training step: frozen IR-50 forward on {a.batch}x{a.length} frames "
-                                   f"of {a.hw}x{a.hw} + TCN/fusion/regressor forward+backward + CE + fused Nesterov SGD; "
-                                   + ("VGGish (log-mel of 1 s PCM, 32 examples/clip) and BERT-base (64-token sentence) run on "
-                                      "the GPU inside the step" if a.encoders == "on" else
-                                      "vggish/bert as pre-computed per-frame features (as the reference trainer feeds them)"),
-                       "encoders_on_gpu": a.encoders == "on",
-                       "clips_per_gpu": a.batch, "global_batch": a.batch * world, "frames_per_clip": a.length,
-                       "frame_hw": a.hw, "n_classes": 7, "released_encoder_groups": a.release,
-                       "trainable_parameters": int(sum(p.numel() for p in ddp.params)), "conv_precision": a.precision, "parallelism": f"dp{world} over clips, flat-bucket RCCL all-reduce",
-                       "loss": float(loss.item())},
-            "roofline": roofline,
-        }
-        if alt is not None:
-            res["fp32_path"] = alt
+        out = {"metric": "training clips/sec (32-frame tri-modal clip)", "value": res["value"], "unit": "clips/s",
+               "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
+               "config": res["config"], "roofline": res["roofline"]}
+        if others:
+            out["roofline"]["other_configs"] = others
         if world == 1 and not a.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(a.hw, a.length, a.encoders == "on")
-        print(json.dumps(res), flush=True)
+            out["cpu_baseline"] = cpu_baseline(a.hw, a.length, a.encoders == "on")
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

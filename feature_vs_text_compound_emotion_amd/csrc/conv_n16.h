@@ -1,0 +1,24 @@
+// conv_n16.h -- types and the MFMA wrapper shared by the narrow (single 16-bit plane) conv kernels.
+#pragma once
+#include "conv_common.h"
+
+namespace cer {
+
+typedef __bf16 n_bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 n_f16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int n_u32x4 __attribute__((ext_vector_type(4)));
+typedef float n_f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void *n_lds_ptr_t;
+
+template <bool F16>
+__device__ __forceinline__ n_f32x4 mfma_n16(const n_u32x4 a, const n_u32x4 b, const n_f32x4 c) {
+    if constexpr (F16)
+        return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(n_f16x8, a), __builtin_bit_cast(n_f16x8, b), c, 0, 0, 0);
+    else
+        return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(n_bf16x8, a), __builtin_bit_cast(n_bf16x8, b), c, 0, 0, 0);
+}
+
+int conv_n16_patch_launch(int tile, const ConvArgs &a, hipStream_t st);  // conv_n16_patch.hip
+bool conv_n16_patch_ok(const ConvArgs &a, int tile);                     // can the patch kernel `tile` take this conv?
+
+}  // namespace cer

@@ -1,0 +1,291 @@
+// conv_n16_patch.hip -- 3x3 / stride 1 / pad 1 convolution on narrow operands with the INPUT WINDOW RESIDENT IN LDS.
+//
+// Why.  PMC of the flat implicit-GEMM kernel (conv_n16.hip; profiles/round2_pmc_conv_n16.txt): the matrix pipes are busy a
+// third of the time and 41 % of the wave cycles are parked at the vmcnt/barrier.  A flat M tile re-fetches its activation
+// rows once per filter tap -- nine L2 -> LDS transfers of every input line, a fifth of which miss the XCD's 4 MiB L2
+// because the kh-shifted re-reads come three steps (several MiB of other traffic) later; a 1-KiB DMA piece spans 8
+// lines, so most pieces wait for a miss.  The kernel below fetches each input line ONCE per block:
+//
+//   * a block owns a 16 x 16 patch of output pixels of one image and BN output channels;
+//   * per 64-channel chunk the 18 x 18 input window of the patch (halo included; out-of-image pixels come back as zeros
+//     from the range-checked DMA) is brought into LDS by 41 one-KiB LDS-DMA pieces; all nine taps then read their pixel
+//     fragments from it: the fragment of output row r under tap (kh, kw) is the 16 consecutive window pixels
+//     (r + kh) * 18 + kw + (lane & 15).  Those rows start at any alignment, so the bank-conflict swizzle is a function of
+//     the window COLUMN found by exhaustive search (tools/check_swizzle.py: conflict free for kw = 0, 1, 2);
+//   * only the weights stream per step: one BN x 64 slice per (chunk, tap) through a 3-slot ring, two steps ahead with
+//     a counted vmcnt; every block of a launch reads the same slices, so they are L2 hits with short latency, while the
+//     long-latency window of the NEXT chunk is fetched a whole chunk (nine steps) ahead into the second window buffer;
+//   * the nine taps are unrolled (tap, ring slot and the next slice's tap are compile-time), fragment reads run two
+//     MFMA groups ahead and the DMA pieces are placed between MFMA groups, as in conv_n16_kernel.
+//
+// L2 -> LDS bytes per 256 pixels x 64 channels x 9 taps: 41 KiB of window + 9 weight slices, against 9 x 32 KiB of
+// activations + the same 9 slices for the flat 256-row tile.
+#include "conv_n16.h"
+
+namespace cer {
+
+// slot = chunk ^ PATCH_F[window column], 3 bits per column (tools/check_swizzle.py: patch_table_constant())
+constexpr unsigned long long PATCH_F_TABLE = 0xd92dad912240ull;
+__device__ __forceinline__ int patch_f(int wx) { return (int)((PATCH_F_TABLE >> (3 * wx)) & 7ull); }
+
+template <int BN, int WP, int WC, int XBUFS, bool F16>
+__global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArgs p) {
+    constexpr int NW = WP * WC, NT = NW * 64;
+    constexpr int PH = 16, PWD = 16, WW = 18, WROWS = 18 * 18;    // patch and window geometry
+    constexpr int XPIECES = (WROWS + 7) / 8;                       // 41 one-KiB pieces (328 rows, the last 4 unused)
+    constexpr int XPW = (XPIECES + NW - 1) / NW;                   // window pieces per wave and chunk
+    constexpr int XBYTES = XPIECES * 1024;
+    constexpr int WSLICE = BN * 128, RING = 3;
+    static_assert(BN % (8 * NW) == 0, "weight-slice pieces are dealt round-robin to the waves");
+    constexpr int WQ = BN / (8 * NW);                               // weight pieces per wave and step
+    constexpr int TP = PH / WP, TC = BN / (16 * WC);                // 16x16 MFMA tiles per wave: output rows x cout tiles
+    static_assert(PH % WP == 0 && XBUFS >= 1 && XBUFS <= 2 && (XBUFS == 1 || XPW <= 9), "geometry");
+    constexpr int WOFF = XBUFS * XBYTES, SINK = WOFF + RING * WSLICE;  // LDS map: windows | weight ring | 1 KiB sink
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NGRP = 2 * TP;                                    // MFMA groups (kk, b) per step, TC MFMAs each
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem_n16p[];
+    unsigned char *smem = reinterpret_cast<unsigned char *>(smem_n16p);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave % WP, wc = wave / WP;
+    const int kg = lane >> 4, l15 = lane & 15;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {   // XCD-aware remap (bijective): blocks that share an XCD's L2 take neighbouring patches
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % p.tiles_n, patch = bid / p.tiles_n;
+    const int pxn = p.W / PWD, pyn = p.H / PH;
+    const int px = patch % pxn, py = (patch / pxn) % pyn, n = patch / (pxn * pyn);
+    const int c0 = tile_n * BN;
+    const int cin_steps = p.cin_steps;
+
+    // ---- DMA assignment ----
+    // window: wave w moves pieces w, w + NW, ...; in a piece lane l owns window row 8 * piece + l / 8 = (wy, wx), LDS slot
+    // l % 8, and fetches source chunk slot ^ PATCH_F[wx]; offsets are relative to the image's first pixel
+    const int prow = lane >> 3, slot = lane & 7;
+    unsigned x_off[XPW];
+    bool x_real[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int q = wave + NW * i;
+        const int row = q * 8 + prow;
+        const int wy = row / WW, wx = row - wy * WW;
+        const int iy = py * PH - 1 + wy, ix = px * PWD - 1 + wx;
+        const bool inb = q < XPIECES && row < WROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        x_real[i] = q < XPIECES;
+        x_off[i] = inb ? (unsigned)(((size_t)iy * p.W + ix) * p.x_ld * 2 + ((slot ^ patch_f(wx)) << 4)) : OOB;
+    }
+    unsigned w_off[WQ];
+#pragma unroll
+    for (int i = 0; i < WQ; ++i) {
+        const int row = (wave + NW * i) * 8 + prow;
+        w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ ((row >> 1) & 7)) << 3)) * 2) : OOB;
+    }
+    const char *ximg = reinterpret_cast<const char *>(p.x_hi) + (size_t)n * p.H * p.W * p.x_ld * 2;
+    const char *wpanel = reinterpret_cast<const char *>(p.w_hi) + (size_t)c0 * p.Kpad * 2;
+
+    // window piece i of chunk cc into window buffer cc % XBUFS (or a zero piece into the sink: keeps the per-step DMA
+    // count of a wave constant, which the counted vmcnt relies on)
+    auto issue_x = [&](int i, int cc) {
+        const bool real = x_real[i] && cc < cin_steps;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ximg) + (size_t)cc * 128, 0, (int)OOB, 0x00020000);
+        unsigned char *dst = real ? smem + (XBUFS == 2 ? (cc & 1) * XBYTES : 0) + (wave + NW * i) * 1024 : smem + SINK;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (n_lds_ptr_t)dst, 16, (int)(real ? x_off[i] : OOB), 0, 0, 0);
+    };
+    // weight slice (cc, tap) into ring slot `ring` (zeros into the sink past the end of the K loop)
+    auto issue_w = [&](int cc, int tap, int ring) {
+        const bool real = cc < cin_steps;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(wpanel) + ((size_t)tap * p.Cin + (size_t)cc * 64) * 2, 0, (int)OOB, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < WQ; ++i) {
+            unsigned char *dst = real ? smem + WOFF + ring * WSLICE + (wave + NW * i) * 1024 : smem + SINK;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (n_lds_ptr_t)dst, 16, (int)(real ? w_off[i] : OOB), 0, 0, 0);
+        }
+    };
+
+    n_f32x4 acc[TC][TP];
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+
+    // ---- fragment address bases ----
+    // weights: row = cout, slot = chunk ^ ((row >> 1) & 7); pixels: window row (r + kh) * 18 + kw + l15 with output row
+    // r = b * WP + wp, slot = chunk ^ PATCH_F[kw + l15]  (second 32-deep half: ^ 64 bytes)
+    const int arow = WOFF + (wc * TC * 16 + l15) * 128 + ((kg ^ ((l15 >> 1) & 7)) << 4);
+    int bcol[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) bcol[kw] = (wp * WW + kw + l15) * 128 + ((kg ^ patch_f(kw + l15)) << 4);
+
+    // ---- prologue: the whole window of chunk 0, weight slices of steps 0 and 1 ----
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) issue_x(i, 0);
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+
+    // One step = one filter tap of one 64-channel chunk.  DMA issued per wave and step: WQ weight pieces (slice of step
+    // s + 2) and, with two window buffers, one window piece of the next chunk during taps 0 .. XPW-1: CNT(tap) pieces.
+    // At the top of step s every piece issued before step s-1 must have landed (slice s was issued in step s-2, the
+    // window of this chunk during the previous chunk / the prologue): vmcnt(CNT(previous tap)).
+    for (int cc = 0; cc < cin_steps; ++cc) {
+        const int xcur = XBUFS == 2 ? (cc & 1) * XBYTES : 0;
+        static_for<9>([&](auto T) {
+            constexpr int tap = decltype(T)::v, kh = tap / 3, kw = tap % 3;
+            constexpr int ptap = (tap + 8) % 9;                                  // the previous step's tap
+            constexpr int pcnt = WQ + ((XBUFS == 2 && ptap < XPW) ? 1 : 0);      // pieces the previous step issued
+            // (lgkmcnt(0): this wave's fragment reads of the previous step have returned before anyone's DMA may
+            // overwrite the slot / window they came from)
+            if (cc == 0 && tap == 0) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");  // prologue: all but slice 1
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            constexpr int ntap = (tap + 2) % 9, nring = (tap + 2) % 3;
+            const int ncc = cc + (tap + 2 >= 9 ? 1 : 0);
+            const unsigned char *Wr = smem + (tap % 3) * WSLICE;
+            const unsigned char *Xb = smem + xcur + kh * (WW * 128);
+            auto lda = [&](int a, int kk) { return *reinterpret_cast<const n_u32x4 *>(Wr + ((arow + a * 16 * 128) ^ (kk << 6))); };
+            auto ldb = [&](int b, int kk) { return *reinterpret_cast<const n_u32x4 *>(Xb + ((bcol[kw] + b * WP * WW * 128) ^ (kk << 6))); };
+            n_u32x4 af[2][TC], bf[NGRP];
+#pragma unroll
+            for (int a = 0; a < TC; ++a) af[0][a] = lda(a, 0);
+            bf[0] = ldb(0, 0);
+            bf[1] = ldb(1 % TP, 1 / TP);
+            static_for<NGRP>([&](auto G) {
+                constexpr int g = decltype(G)::v, kk = g / TP, b = g % TP;
+                if constexpr (g + 2 < NGRP) bf[g + 2] = ldb((g + 2) % TP, (g + 2) / TP);
+                if constexpr (g == 0) {
+#pragma unroll
+                    for (int a = 0; a < TC; ++a) af[1][a] = lda(a, 1);
+                }
+                if constexpr (g == 0) issue_w(ncc, ntap, nring);
+                if constexpr (g == 2 % NGRP && XBUFS == 2 && tap < XPW) issue_x(tap, cc + 1);
+#pragma unroll
+                for (int a = 0; a < TC; ++a) acc[a][b] = mfma_n16<F16>(af[kk][a], bf[g], acc[a][b]);
+            });
+            // issue order: TC MFMAs of group g, then the reads for group g+2 and the group's DMA pieces (see conv_n16.hip)
+            __builtin_amdgcn_sched_group_barrier(0x100, TC + 2, 0);
+            static_for<NGRP>([&](auto G) {
+                constexpr int g = decltype(G)::v;
+                __builtin_amdgcn_sched_group_barrier(0x008, TC, 0);
+                constexpr int nread = (g + 2 < NGRP ? 1 : 0) + (g == 0 ? TC : 0);
+                if constexpr (nread > 0) __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);
+                constexpr int npiece = (g == 0 ? WQ : 0) + ((g == 2 % NGRP && XBUFS == 2 && tap < XPW) ? 1 : 0);
+                if constexpr (npiece > 0) __builtin_amdgcn_sched_group_barrier(0x010, npiece, 0);
+            });
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sink pieces of the last steps
+
+    // ---- epilogue: accumulators -> LDS (fp32, 16-byte granules XOR-swizzled by the row) -> compact coalesced loop ----
+    constexpr int G = BN / 4, RPI = NT / G;
+    static_assert(NT % G == 0 && RPI == 16 && 256 * BN * 4 <= SINK, "one patch row of 16 pixels per loop iteration; one pass");
+    float *Ct = reinterpret_cast<float *>(smem_n16p);
+    const int g = tid % G, ox = tid / G;   // this thread's cout granule and patch column
+    const int c = c0 + g * 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();  // the fragment reads of the last step are done
+    static_for<TP>([&](auto B) {
+        constexpr int b = decltype(B)::v;
+        const int ml = (b * WP + wp) * 16 + l15;
+        static_for<TC>([&](auto A) {
+            constexpr int a = decltype(A)::v;
+            const int gg = (wc * TC + a) * 4 + kg;
+            *reinterpret_cast<n_f32x4 *>(Ct + ml * BN + ((gg ^ (ml & 15)) << 2)) = acc[a][b];
+        });
+    });
+    __syncthreads();
+    const int gx = px * PWD + ox;
+    const int rx = gx == 0 ? 0 : (gx == p.W - 1 ? 2 : 1);
+    const size_t pix0 = ((size_t)n * p.H + (size_t)py * PH) * p.W + gx;
+    for (int oy = 0; oy < PH; ++oy) {
+        const int ml = oy * 16 + ox;
+        const int m = (int)(pix0 + (size_t)oy * p.W);
+        const n_f32x4 q = *reinterpret_cast<const n_f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2));
+        float v[4] = {q[0], q[1], q[2], q[3]};
+        if (c < p.Cout) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s1[t] += v[t];
+                s2[t] += v[t] * v[t];
+            }
+            const float *brow_ = p.bias;
+            if (p.bias9) {
+                const int gy = py * PH + oy;
+                const int ry = gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1);
+                brow_ = p.bias9 + (size_t)(3 * ry + rx) * p.Cout;
+            }
+            epilogue_store4(p, m, c, v, brow_);
+        }
+    }
+    if (p.stats) {
+        __syncthreads();  // Ct has been consumed
+        float *red = reinterpret_cast<float *>(smem_n16p);  // [RPI][2][BN]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            red[(ox * 2 + 0) * BN + g * 4 + t] = s1[t];
+            red[(ox * 2 + 1) * BN + g * 4 + t] = s2[t];
+        }
+        __syncthreads();
+        if (tid < BN && c0 + tid < p.Cout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < RPI; ++w) {
+                t1 += red[(w * 2 + 0) * BN + tid];
+                t2 += red[(w * 2 + 1) * BN + tid];
+            }
+            p.stats[((size_t)patch * 2 + 0) * p.Cout + c0 + tid] = t1;
+            p.stats[((size_t)patch * 2 + 1) * p.Cout + c0 + tid] = t2;
+        }
+    }
+}
+
+template <int BN, int WP, int WC, int XBUFS>
+static int launch_patch(const ConvArgs &a, hipStream_t st) {
+    constexpr int XPIECES = 41;
+    const size_t lds = (size_t)XBUFS * XPIECES * 1024 + 3 * (size_t)BN * 128 + 1024;
+    const dim3 grid(a.tiles_m * a.tiles_n, 1, 1), block(WP * WC * 64);
+    if (a.narrow == CER_STORE_F16) {
+        auto k = conv_n16_patch_kernel<BN, WP, WC, XBUFS, true>;
+        if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CER_LAUNCH(k, grid, block, lds, st, a);
+    } else {
+        auto k = conv_n16_patch_kernel<BN, WP, WC, XBUFS, false>;
+        if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CER_LAUNCH(k, grid, block, lds, st, a);
+    }
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+// tile ids: 71 = 16x16 patch x 64 couts, 4 waves, ONE window buffer (Cin == 64 only; 74 KiB of LDS -> two blocks per CU, so
+// one block's window fetch overlaps the other's nine steps); 72 = 16x16 patch x 128 couts, 8 waves, two window buffers
+bool conv_n16_patch_ok(const ConvArgs &a, int tile) {
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.dil_h != 1 || a.dil_w != 1 || a.pad_t != 1 || a.pad_l != 1 || a.Ho != a.H ||
+        a.Wo != a.W || (a.H & 15) || (a.W & 15) || (a.Cin & 63) || a.split_k != 1)
+        return false;
+    if ((long long)a.H * a.W * a.x_ld * 2 >= (1ll << 31) || (long long)128 * a.Kpad * 2 >= (1ll << 31)) return false;
+    if (tile == 71) return a.Cin == 64;
+    return tile == 72;
+}
+
+int conv_n16_patch_launch(int tile, const ConvArgs &a, hipStream_t st) {
+    if (!conv_n16_patch_ok(a, tile))
+        return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow, patch kernel): needs a 3x3 / stride 1 / pad 1 conv on images whose "
+                                                   "height and width are multiples of 16, Cin % 64 == 0 (tile 71: Cin == 64), no split-K");
+    switch (tile) {
+        case 71: return launch_patch<64, 4, 1, 1>(a, st);
+        case 72: return launch_patch<128, 4, 2, 2>(a, st);
+        default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (narrow, patch kernel): unknown tile id");
+    }
+}
+
+}  // namespace cer

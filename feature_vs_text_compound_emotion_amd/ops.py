@@ -854,6 +854,10 @@ def bert_embed_ln(ids, word, pos, typ, gamma, beta, eps=1e-12):
     return y
 
 
+# bench.py sets this to a list to time the MFMA attention launches: (kind, algorithmic FLOPs, start event, end event)
+ATTN_TRACE = None
+
+
 def attention(q, k, v, out, batch, heads, sq, sk, d, q_strides, k_strides, v_strides, o_strides, scale, key_mask=None,
               lse=None):
     """Strided attention: element (b, s, h, :) at base + b*st[0] + s*st[1] + h*st[2].  q/k/v/out are
@@ -864,9 +868,15 @@ def attention(q, k, v, out, batch, heads, sq, sk, d, q_strides, k_strides, v_str
     if key_mask is not None and not (key_mask.is_cuda and key_mask.dtype == torch.int32 and key_mask.is_contiguous()):
         raise ValueError("key_mask: expected a contiguous int32 GPU tensor [B, Sk]")
     LL3 = ctypes.c_longlong * 3
+    if ATTN_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_lib.load().cer_attention_fwd(ptr(q), ptr(k), ptr(v), ptr(key_mask), ptr(out), ptr(lse), batch, heads, sq, sk, d,
                                         LL3(*q_strides), LL3(*k_strides), LL3(*v_strides), LL3(*o_strides), scale,
                                         current_stream()), "cer_attention_fwd")
+    if ATTN_TRACE is not None:
+        e1.record()
+        ATTN_TRACE.append(("fwd", 4.0 * batch * heads * sq * sk * d, e0, e1))
     return out
 
 
@@ -878,11 +888,17 @@ def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, batch, heads, sq, sk, d, 
             raise ValueError(f"{n}: expected a float32 GPU tensor")
     LL3 = ctypes.c_longlong * 3
     delta = torch.empty_like(lse)
+    if ATTN_TRACE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     check(_lib.load().cer_attention_bwd(ptr(q), ptr(k), ptr(v), ptr(out), ptr(dout), ptr(lse), ptr(key_mask), ptr(delta),
                                         ptr(dq), ptr(dk), ptr(dv), batch, heads, sq, sk, d, LL3(*q_strides),
                                         LL3(*k_strides), LL3(*v_strides), LL3(*o_strides), LL3(*do_strides),
                                         LL3(*dq_strides), LL3(*dk_strides), LL3(*dv_strides), scale, current_stream()),
           "cer_attention_bwd")
+    if ATTN_TRACE is not None:
+        e1.record()
+        ATTN_TRACE.append(("bwd", 8.0 * batch * heads * sq * sk * d, e0, e1))
 
 
 def add_inplace(y, x):

@@ -54,7 +54,15 @@ def test_to_n16_is_round_to_nearest_even_and_from_n16_is_exact():
     (2, 128, 256, 10, 3, 1, 64), (5, 64, 128, 9, 3, 2, 64), (3, 64, 100, 7, 3, 1, 64),
     (3, 64, 64, 12, 3, 1, 65), (3, 64, 96, 7, 3, 1, 65),
     (3, 64, 96, 7, 3, 1, 66), (1, 64, 40, 5, 3, 1, 66),
-    (2, 256, 256, 10, 3, 1, 67), (2, 128, 256, 10, 3, 2, 67)])
+    (2, 256, 256, 10, 3, 1, 67), (2, 128, 256, 10, 3, 2, 67),
+    # patch kernels (input window of a 16x16 output patch resident in LDS across the nine taps): image borders on every
+    # side of a patch, several patches per image, ragged Cout, 1 / 2 / 4 channel chunks, two cout tiles per patch
+    (2, 64, 64, 32, 3, 1, 71), (1, 64, 128, 48, 3, 1, 71), (2, 64, 40, 16, 3, 1, 71), (3, 64, 64, 16, 3, 1, 71),
+    (2, 128, 128, 32, 3, 1, 72), (1, 128, 256, 32, 3, 1, 72), (1, 256, 128, 16, 3, 1, 72), (3, 64, 100, 32, 3, 1, 72),
+    (1, 192, 128, 48, 3, 1, 72),
+    # DMA-placement A/B variants of the flat kernels
+    (4, 128, 256, 10, 3, 1, 81), (4, 128, 128, 10, 3, 1, 82), (3, 64, 64, 12, 3, 1, 83), (2, 128, 256, 10, 3, 1, 84),
+    (4, 128, 256, 10, 3, 1, 91), (7, 256, 512, 5, 3, 2, 91), (2, 128, 256, 10, 3, 1, 94)])
 def test_conv_n16_matches_float64_on_the_same_operands(n, cin, cout, hw, k, stride, tile, dtype):
     from feature_vs_text_compound_emotion_amd import ops
     x, w = _setup(n, cin, cout, hw, k, n * 100 + cin + cout, dtype)
@@ -71,6 +79,51 @@ def test_conv_n16_matches_float64_on_the_same_operands(n, cin, cout, hw, k, stri
     st = r["stats"].cpu().double().sum(0)
     assert (st[0] - ref.sum((0, 2, 3))).abs().max().item() < 1e-2
     assert (st[1] - (ref * ref).sum((0, 2, 3))).abs().max().item() < 1e-2
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,tile", [(64, 64, 71), (64, 128, 71), (128, 128, 72), (64, 200, 72), (64, 64, 0), (128, 128, 0)])
+def test_conv_n16_patch_kernel_epilogue_on_non_square_images(cin, cout, tile, dtype):
+    """Patch kernels: H != W, bias9 (folded input BatchNorm) + PReLU + narrow residual + statistics; and the automatic
+    choice on a shape the picker routes to them."""
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    n, h, w = (176, 32, 48) if tile == 0 else (2, 32, 48)   # tile 0: enough patches for the picker to choose a patch kernel
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(dtype)
+    s1, t1 = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.5
+    alpha = torch.rand(cout, generator=g) * 0.3 + 0.1
+    res = torch.randn(n, cout, h, w, generator=g).to(dtype)
+    wp, b9 = ops.fold_input_bn_3x3(wt.float().cuda(), s1.cuda(), t1.cuda())
+    wn = ops.to_n16(wp, dtype)
+    w_eff = (wt.float() * s1.view(1, -1, 1, 1)).to(dtype).double()
+    shift_img = torch.ones(1, cin, h, w, dtype=torch.float64) * t1.double().view(1, -1, 1, 1)
+    raw = F.conv2d(x.double(), w_eff, None, 1, 1)
+    z = raw + F.conv2d(shift_img, wt.double(), None, 1, 1)
+    ref = torch.where(z >= 0, z, z * alpha.double().view(1, -1, 1, 1)) + res.double()
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    rd = res.permute(0, 2, 3, 1).contiguous().cuda()
+    r = ops.conv2d_n16(xd, wn, 3, 3, pad=(1, 1), alpha=alpha.cuda(), act1=ops.ACT_PRELU, bias9=b9, residual=rd, tile=tile,
+                       out_f32=True, want_stats=True)
+    assert (r["y"].cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item() < 3e-5
+    assert torch.equal(r["n16"].cpu(), r["y"].cpu().to(dtype))
+    st = r["stats"].cpu().double().sum(0)
+    assert (st[0] - raw.sum((0, 2, 3))).abs().max().item() < 2e-2
+    assert (st[1] - (raw * raw).sum((0, 2, 3))).abs().max().item() < 2e-2
+
+
+def test_conv_n16_patch_kernel_rejects_what_it_cannot_take():
+    from feature_vs_text_compound_emotion_amd import ops
+    x = torch.zeros(1, 20, 20, 64, dtype=torch.bfloat16).cuda()
+    w = torch.zeros(64, ops.conv_kpad(3, 3, 64), dtype=torch.bfloat16).cuda()
+    with pytest.raises(RuntimeError, match="patch"):
+        ops.conv2d_n16(x, w, 3, 3, pad=(1, 1), tile=71)          # 20 is not a multiple of 16
+    x = torch.zeros(1, 32, 32, 128, dtype=torch.bfloat16).cuda()
+    w = torch.zeros(64, ops.conv_kpad(3, 3, 128), dtype=torch.bfloat16).cuda()
+    with pytest.raises(RuntimeError, match="patch"):
+        ops.conv2d_n16(x, w, 3, 3, pad=(1, 1), tile=71)          # tile 71 keeps ONE window: Cin == 64 only
+    with pytest.raises(RuntimeError, match="patch"):
+        ops.conv2d_n16(x, w, 3, 3, stride=2, pad=(1, 1), tile=72)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

@@ -31,6 +31,7 @@ def main():
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--only", default="")
     ap.add_argument("--b3", action="store_true", help="bf16x3 kernel (split hi/lo operands)")
+    ap.add_argument("--n16", choices=["bf16", "fp16"], default=None, help="narrow kernel (one 16-bit plane per operand)")
     a = ap.parse_args()
     scale = a.hw / 40
     for name, cin, cout, h, k, stride in SHAPES:
@@ -41,6 +42,32 @@ def main():
         w = torch.randn(cout, ops.conv_kpad(k, k, cin), device="cuda") * 0.02
         ho = (h + 2 * (k // 2) - k) // stride + 1
         flops = 2.0 * a.frames * ho * ho * cout * cin * k * k
+        if a.n16:
+            dt = torch.bfloat16 if a.n16 == "bf16" else torch.float16
+            xs, ws = ops.to_n16(x, dt), ops.to_n16(w, dt)
+            del x
+            for tile in [int(t) for t in a.tiles.split(",")]:
+                run = lambda: ops.conv2d_n16(xs, ws, k, k, stride=stride, pad=(k // 2, k // 2), tile=tile)  # noqa: E731
+                try:
+                    for _ in range(2):
+                        run()
+                except RuntimeError as err:
+                    if "UNSUPPORTED" in str(err) or "status -2" in str(err):
+                        print(f"{name:18s} H={h:3d} {a.n16} tile={tile}  unsupported", flush=True)
+                        continue
+                    raise
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / a.iters
+                gb = (xs.numel() * 2 + a.frames * ho * ho * cout * 2) / 1e9
+                print(f"{name:18s} H={h:3d} {a.n16} tile={tile} {ms:8.3f} ms  {flops / ms / 1e9:7.1f} TFLOP/s  "
+                      f"{gb / ms * 1e3:6.0f} GB/s (in+out)", flush=True)
+            continue
         if a.b3:
             xs, ws = ops.split_bf16(x), ops.split_bf16(w)
             for tile in [int(t) for t in a.tiles.split(",")]:

@@ -52,6 +52,27 @@ def n16_dma_image_is_a_permutation(rows=256):
     return all(addr == row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4) for (row, chunk), addr in seen.items())
 
 
+# conv_n16_patch_kernel: the input window of a 16 x 16 output patch is 18 x 18 pixels of 128 bytes (row = wy * 18 + wx); the
+# fragment of output row r under tap (kh, kw) is the 16 consecutive window pixels (r + kh) * 18 + kw + (lane & 15).  18 is
+# even, so the bank-row half of a pixel is the parity of its window COLUMN wx, and the swizzle is a function of wx alone:
+# slot = chunk ^ PATCH_F[wx], found by exhaustive search so that the reads are conflict free for kw = 0, 1 and 2.
+PATCH_F = [0, 0, 1, 1, 2, 2, 4, 4, 5, 5, 6, 6, 2, 2, 6, 6, 0, 0]
+
+
+def patch_fragment_addr(lane, out_row, kh, kw, kk):
+    wx = kw + (lane & 15)
+    row = (out_row + kh) * 18 + wx
+    chunk = (lane >> 4) + 4 * kk
+    return row * 128 + ((chunk ^ PATCH_F[wx]) << 4)
+
+
+def patch_table_constant():
+    v = 0
+    for i, f in enumerate(PATCH_F):
+        v |= f << (3 * i)
+    return v
+
+
 def main():
     ok = True
     for base in range(0, 256, 16):          # fragment tiles start at multiples of 16 rows
@@ -62,6 +83,9 @@ def main():
     okb = all(worst_way(lambda l: b3_fragment_addr(l, base)) == 1 for base in range(0, 256, 16))
     print("conv_b3 fragment reads conflict free:", okb)
     print("conv_n16 DMA image is the permutation the reads expect:", n16_dma_image_is_a_permutation())
+    okp = all(worst_way(lambda l: patch_fragment_addr(l, r, kh, kw, kk)) == 1
+              for r in range(16) for kh in range(3) for kw in range(3) for kk in (0, 1))
+    print("conv_n16 patch-window fragment reads conflict free (all rows, taps):", okp, hex(patch_table_constant()))
 
 
 if __name__ == "__main__":
