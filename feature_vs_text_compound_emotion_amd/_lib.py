@@ -74,7 +74,7 @@ _SIGNATURES = {
     "cer_lfan_attn_bwd": (c_int, [POINTER(_P), _P, _P, POINTER(_P), c_int, c_int, c_int, c_int, _P]),
     "cer_layernorm_fwd": (c_int, [_P, _P, _P, _P, _P, c_int, _P, _P, c_int, c_int, c_float, _P]),
     "cer_layernorm_bwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
-    "cer_cross_entropy": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
+    "cer_cross_entropy": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, _P]),
     "cer_dropout_mask": (c_int, [_P, c_size_t, c_float, c_uint64, c_uint64, _P]),
     "cer_copy_cols": (c_int, [_P, c_int, _P, c_int, c_int, c_int, _P]),
     "cer_leaky_relu_fwd": (c_int, [_P, _P, c_size_t, c_float, _P]),
@@ -86,6 +86,8 @@ _SIGNATURES = {
     "cer_bert_embed_ln": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_float, _P]),
     "cer_attention_fwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, c_float, _P]),
     "cer_attention_bwd": (c_int, [_P] * 11 + [c_int] * 5 + [_P] * 8 + [c_float, _P]),
+    "cer_window_stitch": (c_int, [_P, _P, c_int, c_int, c_int, c_int, _P, _P]),
+    "cer_eval_accumulate": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P]),
     "cer_add_inplace": (c_int, [_P, _P, c_size_t, _P]),
     "cer_l2norm_rows": (c_int, [_P, _P, c_int, c_int, _P]),
     "cer_l2norm_rows_bwd": (c_int, [_P, _P, _P, c_int, c_int, _P]),

@@ -16,6 +16,11 @@ __device__ __forceinline__ float wave_sum(float v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
     return v;
 }
+__device__ __forceinline__ int wave_sum_int(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
 
 // ------------------------------------------------------------- weight norm
 // w = g * v / ||v||, one wave per output channel (row of E = Cin*k elements).
@@ -333,14 +338,49 @@ __global__ void layernorm_bwd_kernel(const float *__restrict__ dy, int dy_ld, co
 
 // ------------------------------------------------------------- cross entropy (mean) fwd + bwd
 // Reference experiment.py:133 + trainer.py:380-383: labels arrive as float32 and are cast to long.
-// Single block: loss = mean_r (lse_r - z_r[y_r]); dlogits = (softmax - onehot)/R.
+// Single block: loss = sum over valid rows (lse_r - z_r[y_r]) / n_valid; dlogits = (softmax - onehot) / n_valid.
+// nn.CrossEntropyLoss semantics for the label values: ignore_index = -100 rows are skipped (zero gradient, not counted);
+// any other label outside [0, C) -- or a NaN -- is an error: torch raises, here the row is never dereferenced, the loss and
+// that row's gradient become NaN (the step fails visibly) and *bad_labels counts such rows for the host wrapper to raise on.
 __global__ void cross_entropy_kernel(const float *__restrict__ logits, const float *__restrict__ labels,
-                                     float *__restrict__ loss, float *__restrict__ dlogits, int R, int C) {
+                                     float *__restrict__ loss, float *__restrict__ dlogits, int *__restrict__ bad_labels,
+                                     int R, int C) {
     __shared__ float red[16];
+    __shared__ int redn[16], redb[16];
+    __shared__ float s_inv;
+    // pass 1: count valid / bad rows (the gradient scale 1 / n_valid is needed before any row is written)
+    int nvalid = 0, nbad = 0;
+    for (int r = threadIdx.x; r < R; r += blockDim.x) {
+        const float lf = labels[r];
+        const bool ignore = lf == -100.f;
+        const bool ok = lf >= 0.f && lf < (float)C;  // false for NaN
+        nvalid += ok ? 1 : 0;
+        nbad += (!ok && !ignore) ? 1 : 0;
+    }
+    nvalid = wave_sum_int(nvalid);
+    nbad = wave_sum_int(nbad);
+    if ((threadIdx.x & 63) == 0) { redn[threadIdx.x >> 6] = nvalid; redb[threadIdx.x >> 6] = nbad; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int tn = 0, tb = 0;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) { tn += redn[i]; tb += redb[i]; }
+        if (bad_labels) *bad_labels = tb;
+        s_inv = tb > 0 ? __int_as_float(0x7fc00000) : 1.f / (float)tn;  // all rows ignored: 0/0 = NaN, as torch
+        redn[0] = tb;
+    }
+    __syncthreads();
+    const float inv = s_inv;
     float acc = 0.f;
     for (int r = threadIdx.x; r < R; r += blockDim.x) {
         const float *z = logits + (size_t)r * C;
-        const int y = (int)labels[r];
+        const float lf = labels[r];
+        const bool ok = lf >= 0.f && lf < (float)C;
+        if (!ok) {  // ignored (zero gradient) or invalid (NaN gradient through inv)
+            if (dlogits)
+                for (int c = 0; c < C; ++c) dlogits[(size_t)r * C + c] = lf == -100.f ? 0.f : inv;
+            continue;
+        }
+        const int y = (int)lf;
         float mx = -INFINITY;
         for (int c = 0; c < C; ++c) mx = fmaxf(mx, z[c]);
         float den = 0.f;
@@ -348,7 +388,7 @@ __global__ void cross_entropy_kernel(const float *__restrict__ logits, const flo
         const float lse = logf(den) + mx;
         acc += lse - z[y];
         if (dlogits)
-            for (int c = 0; c < C; ++c) dlogits[(size_t)r * C + c] = (expf(z[c] - lse) - (c == y ? 1.f : 0.f)) / (float)R;
+            for (int c = 0; c < C; ++c) dlogits[(size_t)r * C + c] = (expf(z[c] - lse) - (c == y ? 1.f : 0.f)) * inv;
     }
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
@@ -356,7 +396,7 @@ __global__ void cross_entropy_kernel(const float *__restrict__ logits, const flo
     if (threadIdx.x == 0) {
         float t = 0.f;
         for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += red[i];
-        *loss = t / (float)R;
+        *loss = t * inv;
     }
 }
 
@@ -626,10 +666,10 @@ extern "C" int cer_layernorm_bwd(const float *dy, int dy_ld, const float *x, con
     return cer_col_sum(dy, dy_ld, nullptr, 0, nullptr, nullptr, dbeta, R, C, workspace, workspace_bytes, stream);
 }
 
-extern "C" int cer_cross_entropy(const float *logits, const float *labels, float *loss, float *dlogits, int R, int C,
-                                 void *stream) {
+extern "C" int cer_cross_entropy(const float *logits, const float *labels, float *loss, float *dlogits, int *bad_labels, int R,
+                                 int C, void *stream) {
     if (!logits || !labels || !loss || R <= 0 || C <= 0) return cer_set_error(CER_ERR_INVALID_ARG, "cross_entropy: bad argument");
-    CER_LAUNCH(cross_entropy_kernel, dim3(1), dim3(1024), 0, ST, logits, labels, loss, dlogits, R, C);
+    CER_LAUNCH(cross_entropy_kernel, dim3(1), dim3(1024), 0, ST, logits, labels, loss, dlogits, bad_labels, R, C);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }

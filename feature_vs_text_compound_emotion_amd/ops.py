@@ -760,16 +760,58 @@ def layernorm_bwd(dy, x, gamma, mean, rstd, mask=None):
     return dx, dg, db
 
 
-def cross_entropy(logits2d, labels_f32, want_grad=True):
-    """Mean CE over rows; labels are float32 class ids (cast like ``.long()``).  Returns
-    (loss scalar tensor, dlogits or None)."""
+class _LabelCheck:
+    """Deferred check of the kernel's bad-label counter: the count travels to pinned host memory asynchronously and is
+    looked at on the NEXT call (or by ``flush()``), so validating the labels costs no device synchronisation per step."""
+    pending = []
+
+    @classmethod
+    def push(cls, count_dev):
+        host = torch.empty((1,), dtype=torch.int32, pin_memory=True)
+        host.copy_(count_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        cls.pending.append((host, ev))
+
+    @classmethod
+    def poll(cls, wait=False):
+        keep = []
+        for host, ev in cls.pending:
+            if wait:
+                ev.synchronize()
+            if ev.query():
+                if int(host[0]) != 0:
+                    cls.pending = []
+                    raise IndexError(f"cross_entropy: {int(host[0])} target(s) out of bounds (valid: 0 .. n_classes-1, or "
+                                     "-100 = ignore_index), as nn.CrossEntropyLoss raises; the step's loss is NaN")
+            else:
+                keep.append((host, ev))
+        cls.pending = keep
+
+
+def flush_label_check():
+    """Wait for the outstanding label checks (call before trusting a finished epoch; tests call it)."""
+    _LabelCheck.poll(wait=True)
+
+
+def cross_entropy(logits2d, labels_f32, want_grad=True, check_labels=True):
+    """Mean CE over rows; labels are float32 class ids (cast like ``.long()``), -100 = ignore_index.  Returns
+    (loss scalar tensor, dlogits or None).  Out-of-range labels raise IndexError -- from this call when the counter of an
+    earlier call has arrived, at the latest from ``flush_label_check()``; the affected step's loss is NaN either way."""
     _dev_f32(logits2d, "logits")
     _dev_f32(labels_f32, "labels")
     r, c = logits2d.shape
+    if labels_f32.numel() != r:
+        raise ValueError(f"cross_entropy: {labels_f32.numel()} labels for {r} rows")
     loss = _empty((), logits2d)
     dl = torch.empty_like(logits2d) if want_grad else None
-    check(_lib.load().cer_cross_entropy(ptr(logits2d), ptr(labels_f32), ptr(loss), ptr(dl), r, c, current_stream()),
+    bad = torch.empty((1,), device=logits2d.device, dtype=torch.int32) if check_labels else None
+    if check_labels:
+        _LabelCheck.poll()
+    check(_lib.load().cer_cross_entropy(ptr(logits2d), ptr(labels_f32), ptr(loss), ptr(dl), ptr(bad), r, c, current_stream()),
           "cer_cross_entropy")
+    if check_labels:
+        _LabelCheck.push(bad)
     return loss, dl
 
 

@@ -86,7 +86,7 @@ class Trainer:
         bsz, nfms, d = labels.shape
         assert d == 1, d
         assert outputs.ndim == 3 and tuple(outputs.shape) == (bsz, nfms, self.number_classes), tuple(outputs.shape)
-        loss = self.criterion(outputs.contiguous().view(bsz * nfms, -1), labels.contiguous().view(bsz * nfms))
+        loss = self.criterion(outputs.contiguous().view(bsz * nfms, -1), labels.contiguous().view(bsz * nfms).long())  # trainer.py:380-383
         loss.backward()
         if self.ddp is not None:
             self.ddp.all_reduce_gradients()
@@ -109,16 +109,27 @@ class Trainer:
         windows = windowing(np.arange(sizes[0][1]), self.window_length, self.hop_length)
         return [[{m: _take(m, t, wd) for m, t in data.items()}, wd] for wd in windows]
 
-    def inference_forward_windows(self, data):
-        """Forward a video longer than the model's window: slide, forward, scatter-add, divide by overlap."""
+    def inference_forward_windows(self, data, aggregate="device"):
+        """Forward a video longer than the model's window (trainer.py:832-892).  ``aggregate="device"`` (default): all
+        windows go through the model as ONE batch (eval mode: clips are independent), then one kernel scatter-adds them
+        in window order and divides by the overlap counts (``eval_device.stitch_windows``).  ``aggregate="host"`` is the
+        reference's own sequence -- one forward per window, indexed adds, Counter of the frame indices -- kept as the
+        checker of the device path and for the CPU tests of the window rules."""
         total = _num_frames(*next(iter(data.items())))
-        results, last = [], -1
-        for chunk, wd in self.window_input(data):
+        chunks = self.window_input(data)
+        last = int(chunks[-1][1][-1])
+        assert total == last + 1, f"{total} | {last + 1}"
+        if aggregate == "device":
+            from .eval_device import stitch_windows
+            batch = {m: torch.cat([c[m] for c, _ in chunks], dim=0).contiguous() for m in chunks[0][0]}
+            out = self.model(batch)                                   # [n_windows, window_length, n_cls]
+            assert out.ndim == 3, out.ndim
+            return stitch_windows(out, [int(wd[0]) for _, wd in chunks], total).unsqueeze(0)
+        results = []
+        for chunk, wd in chunks:
             out = self.model({m: t.contiguous() for m, t in chunk.items()})
             assert out.ndim == 3, out.ndim
             results.append((out, wd))
-            last = int(wd[-1])
-        assert total == last + 1, f"{total} | {last + 1}"
         final = torch.zeros((results[-1][0].shape[0], total, results[-1][0].shape[2]), device=results[-1][0].device,
                             dtype=results[-1][0].dtype)
         idx = []
@@ -132,9 +143,20 @@ class Trainer:
         return final
 
     @torch.no_grad()
-    def inference(self, dataloader):
+    def inference(self, dataloader, keep_logits=False, aggregate="device"):
+        """Trainer.inference (trainer.py:436-523).  ``aggregate="device"`` (default): logits stay on the GPU, each video is
+        folded into device-side confusion counts (``DeviceEvalAccumulator``) and the scores come from one small copy at
+        the end; ``keep_logits=True`` additionally returns the reference's per-video ``{labels, logits}`` dictionary (one
+        copy per video).  ``aggregate="host"``: the reference's own flow -- per-video copies, numpy scores
+        (``metrics.compute_perf``) -- the checker of the device path."""
         self.model.eval()
         per_video = {}
+        acc = None
+        if aggregate == "device":
+            from .eval_device import DeviceEvalAccumulator
+            acc = DeviceEvalAccumulator(self.number_classes, self.ignore_classes, device=self.device)
+        elif aggregate != "host":
+            raise ValueError(aggregate)
         for X, trials, lengths, indices in dataloader:
             inputs, labels = self._split(X)
             nframes = 0
@@ -144,11 +166,16 @@ class Trainer:
             if labels.numel() == self.train_batch_size:
                 labels = torch.zeros((self.train_batch_size, len(indices[0]), 1), dtype=torch.float32, device=self.device)
             if nframes > self.window_length and self.model_name == "LFAN":
-                outputs = self.inference_forward_windows(inputs)
+                outputs = self.inference_forward_windows(inputs, aggregate)
             else:
                 outputs = self.model(inputs)
             bsz, nfms, d = labels.shape
             assert d == 1 and tuple(outputs.shape) == (bsz, nfms, self.number_classes), tuple(outputs.shape)
-            per_video[trials[0]] = {"labels": labels.contiguous().view(bsz * nfms).long().cpu().numpy().flatten(),
-                                    "logits": outputs.contiguous().view(bsz * nfms, -1).cpu().numpy()}
+            if acc is not None:
+                acc.add(outputs.contiguous().view(bsz * nfms, -1), labels.contiguous().view(bsz * nfms))
+            if keep_logits or acc is None:
+                per_video[trials[0]] = {"labels": labels.contiguous().view(bsz * nfms).long().cpu().numpy().flatten(),
+                                        "logits": outputs.contiguous().view(bsz * nfms, -1).cpu().numpy()}
+        if acc is not None:
+            return acc.compute(), per_video
         return metrics.compute_perf(per_video, self.ignore_classes), per_video

@@ -254,8 +254,12 @@ int cer_layernorm_bwd(const float *dy, int dy_ld, const float *x, const float *m
                       float *scratch, int R, int C, void *workspace, size_t workspace_bytes, void *stream);
 
 /* nn.CrossEntropyLoss(reduction='mean') on [R,C] logits with FLOAT labels cast to long
- * (reference experiment.py:133, trainer.py:380-383); dlogits may be NULL. */
-int cer_cross_entropy(const float *logits, const float *labels, float *loss, float *dlogits, int R, int C, void *stream);
+ * (reference experiment.py:133, trainer.py:380-383); dlogits may be NULL.  Label semantics as torch: -100 (ignore_index)
+ * rows are skipped (zero gradient, mean over the other rows); any other value outside [0, C), or NaN, is an error:
+ * the row is never dereferenced, loss and that row's gradient become NaN and *bad_labels (device int, may be NULL)
+ * receives the number of such rows, which the host wrapper turns into the exception torch raises. */
+int cer_cross_entropy(const float *logits, const float *labels, float *loss, float *dlogits, int *bad_labels, int R, int C,
+                      void *stream);
 
 /* Train-mode BatchNorm2d inside the vision encoder (the reference's model.train() also puts
  * the frozen IR-50's BatchNorms in batch-statistics mode).
@@ -341,6 +345,26 @@ int cer_attention_bwd(const float *q, const float *k, const float *v, const floa
                       const long long *v_strides, const long long *o_strides, const long long *do_strides,
                       const long long *dq_strides, const long long *dk_strides, const long long *dv_strides,
                       float scale, void *stream);
+
+/* ------------------------------------------------------------------------
+ * Evaluation path on the device (reference trainer.py:436-523, 832-892; metrics.py:43-193).
+ * ---------------------------------------------------------------------- */
+
+/* Stitch the outputs of the sliding inference windows of ONE video (trainer.py:832-892): out[f][c] = sum over the windows
+ * covering frame f, in window order, of win_out[w][f - starts[w]][c], divided by the number of such windows.
+ * win_out [nw][Lw][C], starts [nw] (device int32), out [total][C]. */
+int cer_window_stitch(const float *win_out, const int *starts, int nw, int Lw, int C, int total, float *out, void *stream);
+
+/* Accumulate (+=) the confusion counts of a batch of V videos: logits [R][C] (the videos' frames concatenated), labels [R]
+ * (float class ids), video_offsets [V+1] (device int32 row offsets).  frame_cm [C][C]: counts[label][argmax]; video_cm
+ * [3][C][C]: the same per video for the reference's three frame -> video decisions (majority vote / mean logits / mean
+ * softmax probabilities, metrics.py:118-139); ignore_class >= 0 drops the LAST logit column and skips frames / videos
+ * labelled ignore_class (C-EXPR-DB's 'Other', metrics.py:62-84); video_pred [V][3] (optional) receives the decisions;
+ * *bad counts labels outside [0, C) and videos with mixed labels (the reference asserts on those).  F1 / accuracy / the
+ * normalised confusion matrix are functions of these counts (host side: one [4][C][C] copy per evaluation). */
+int cer_eval_accumulate(const float *logits, const float *labels, const int *video_offsets, int V, int R, int C,
+                        int ignore_class, unsigned long long *frame_cm, unsigned long long *video_cm, int *video_pred, int *bad,
+                        void *stream);
 
 /* y += x */
 int cer_add_inplace(float *y, const float *x, size_t n, void *stream);

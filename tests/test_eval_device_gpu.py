@@ -1,0 +1,123 @@
+"""Device-side evaluation aggregation vs the host mirror of the reference's numpy flow
+(feature_vs_text_compound_emotion_amd/metrics.py <- reference metrics.py:43-193, trainer.py:832-892)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _videos(seed, n_videos, n_cls, sharp=3.0):
+    rng = np.random.default_rng(seed)
+    data, order = {}, []
+    for v in range(n_videos):
+        n = int(rng.integers(5, 400))
+        label = int(rng.integers(0, n_cls))
+        logits = rng.standard_normal((n, n_cls)).astype(np.float32)
+        logits[:, label] += rng.random() * sharp       # some videos are classified right, some are not
+        data[f"v{v}"] = {"labels": np.full(n, label, dtype=np.int64), "logits": logits}
+        order.append(f"v{v}")
+    return data, order
+
+
+def _same(a, b):
+    if isinstance(a, dict):
+        assert set(a) == set(b)
+        for k in a:
+            _same(a[k], b[k])
+    elif a is None:
+        assert b is None
+    else:
+        assert np.allclose(np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64), atol=1e-12), (a, b)
+
+
+@pytest.mark.parametrize("n_cls,ignore", [(7, (None,)), (8, (None, 7))])
+def test_device_confusion_counts_give_the_reference_scores(n_cls, ignore):
+    from feature_vs_text_compound_emotion_amd import metrics
+    from feature_vs_text_compound_emotion_amd.eval_device import DeviceEvalAccumulator
+    data, order = _videos(n_cls, 60, n_cls)
+    host = metrics.compute_perf(data, ignore)
+    acc = DeviceEvalAccumulator(n_cls, ignore, keep_video_predictions=True)
+    # half of the videos one by one, the rest as one concatenated batch with offsets
+    for k in order[:30]:
+        acc.add(torch.from_numpy(data[k]["logits"]).cuda(), torch.from_numpy(data[k]["labels"]).cuda())
+    rest = order[30:]
+    off = np.cumsum([0] + [len(data[k]["labels"]) for k in rest]).tolist()
+    acc.add(torch.from_numpy(np.concatenate([data[k]["logits"] for k in rest])).cuda(),
+            torch.from_numpy(np.concatenate([data[k]["labels"] for k in rest])).float().cuda(), video_offsets=off)
+    _same(acc.compute(), host)
+    # the per-video decisions themselves (vote / mean logits / mean probabilities)
+    vp = [p for ic, p in acc.video_predictions if ic is None]
+    got = torch.cat(vp).cpu().numpy()
+    preds, _ = metrics.format_trg_pred_video(data, None)
+    want = np.array([[p[metrics.FRM_VOTE], p[metrics.FRM_AVG_LOGITS], p[metrics.FRM_AVG_PROBS]] for p in preds])
+    assert np.array_equal(got, want)
+
+
+def test_majority_vote_tie_goes_to_the_class_seen_first_like_counter_most_common():
+    from feature_vs_text_compound_emotion_amd import metrics
+    from feature_vs_text_compound_emotion_amd.eval_device import DeviceEvalAccumulator
+    frames = [4, 2, 2, 4, 1, 1]                       # 4, 2 and 1 tie with two votes each; 4 was seen first
+    logits = np.eye(7, dtype=np.float32)[frames] * 5
+    data = {"a": {"labels": np.full(6, 4), "logits": logits}}
+    assert metrics.format_trg_pred_video(data, None)[0][0][metrics.FRM_VOTE] == 4
+    acc = DeviceEvalAccumulator(7, keep_video_predictions=True)
+    acc.add(torch.from_numpy(logits).cuda(), torch.full((6,), 4.0).cuda())
+    assert int(acc.video_predictions[0][1][0, 0]) == 4
+
+
+def test_mixed_labels_in_a_video_and_out_of_range_labels_are_errors():
+    from feature_vs_text_compound_emotion_amd.eval_device import DeviceEvalAccumulator
+    acc = DeviceEvalAccumulator(7)
+    acc.add(torch.randn(5, 7).cuda(), torch.tensor([1.0, 1, 2, 1, 1]).cuda())
+    with pytest.raises(AssertionError):
+        acc.compute()
+    acc = DeviceEvalAccumulator(7)
+    acc.add(torch.randn(3, 7).cuda(), torch.tensor([9.0, 9, 9]).cuda())
+    with pytest.raises(AssertionError):
+        acc.compute()
+
+
+def test_window_stitch_matches_the_reference_sequence():
+    from feature_vs_text_compound_emotion_amd.eval_device import stitch_windows
+    from feature_vs_text_compound_emotion_amd.trainer import windowing
+    g = torch.Generator().manual_seed(1)
+    for n, win, hop in ((650, 300, 200), (301, 300, 200), (21, 8, 5), (300, 300, 200)):
+        wds = windowing(np.arange(n), win, hop)
+        outs = torch.randn(len(wds), win, 7, generator=g)
+        final = torch.zeros(n, 7)
+        cnt = torch.zeros(n)
+        for o, wd in zip(outs, wds):          # trainer.py:861-880: add window after window, then divide
+            final[wd] = final[wd] + o
+            cnt[wd] += 1
+        want = final / cnt[:, None]
+        got = stitch_windows(outs.cuda(), [int(w[0]) for w in wds], n).cpu()
+        assert torch.equal(got, want)
+
+
+def test_trainer_inference_device_and_host_aggregation_agree_on_the_hip_model():
+    """Trainer.inference over several videos (one longer than the window) with the HIP LFAN: device-side counts vs the
+    reference's host flow -- identical scores, no per-video copy on the device path."""
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.lfan import LFAN
+    from feature_vs_text_compound_emotion_amd.trainer import Trainer
+    mods = ["vggish", "bert"]
+    sd = synth.lfan_state_dict(mods, n_cls=7, seed=9)
+    model = LFAN(backbone_settings={}, output_dim=7, task="CLASSIFICATION", modality=mods, example_length=8, kernel_size=5,
+                 tcn_channel=synth.TCN_CHANNELS, root_dir="", device="cuda")
+    model.init(load_backbone=False)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().eval()
+    g = torch.Generator().manual_seed(5)
+    loader = []
+    for v, (n, label) in enumerate([(8, 2), (21, 5), (8, 0), (13, 5)]):
+        X = {"vggish": torch.randn(1, 1, n, 128, generator=g), "bert": torch.randn(1, 1, n, 768, generator=g),
+             "EXPR_continuous_label": torch.full((1, n, 1), float(label))}
+        loader.append((X, [f"clip{v}"], [n], [np.arange(n)]))
+    tr = Trainer(model, device="cuda", window_length=8, hop_length=5, number_classes=7)
+    perf_d, pv_d = tr.inference(loader, keep_logits=True)
+    perf_h, pv_h = tr.inference(loader, aggregate="host")
+    _same(perf_d, perf_h)
+    for k in pv_h:
+        assert np.abs(pv_d[k]["logits"] - pv_h[k]["logits"]).max() < 1e-5
+    assert tr.inference(loader)[1] == {}      # default: nothing copied per video

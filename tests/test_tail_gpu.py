@@ -102,6 +102,34 @@ def test_cross_entropy_fwd_bwd():
     _close(ld.grad, logits.grad, 1e-7)
 
 
+def test_cross_entropy_label_semantics_match_torch():
+    """nn.CrossEntropyLoss: ignore_index = -100 rows are skipped (mean over the others, zero gradient); any other label
+    outside [0, C) raises.  The kernel never dereferences such a row; the error surfaces through the deferred counter."""
+    from feature_vs_text_compound_emotion_amd import ops
+    from feature_vs_text_compound_emotion_amd.lfan import cross_entropy_loss
+    g = torch.Generator().manual_seed(41)
+    logits = torch.randn(40, 7, generator=g, requires_grad=True)
+    labels = torch.randint(0, 7, (40,), generator=g)
+    labels[[3, 17, 39]] = -100
+    ref = F.cross_entropy(logits, labels)
+    ref.backward()
+    ld = logits.detach().cuda().requires_grad_(True)
+    loss = cross_entropy_loss(ld, labels.cuda())       # long labels, as the reference's trainer passes them
+    loss.backward()
+    _close(loss, ref, 1e-6)
+    _close(ld.grad, logits.grad, 1e-7)
+    ops.flush_label_check()
+    for bad_value in (7.0, -1.0, float("nan")):   # 7 = the 'Other' class with its column dropped, -1 = ABAW invalid frame
+        bad = labels.float().clone()
+        bad[5] = bad_value
+        with pytest.raises(IndexError, match="out of bounds"):
+            out = cross_entropy_loss(ld.detach(), bad.cuda())
+            assert torch.isnan(out).item()            # the step fails visibly even before the counter arrives
+            ops.flush_label_check()
+    ops.flush_label_check()                           # nothing pending: later calls are clean
+    _close(cross_entropy_loss(ld.detach(), labels.cuda()), ref, 1e-6)
+
+
 def test_dropout_mask_statistics_and_determinism():
     ops = _ops()
     m1 = ops.dropout_mask((1 << 16,), 0.1, 7, 0, "cuda")
@@ -288,7 +316,7 @@ def test_trainer_windowed_inference_on_hip_model_vs_oracle():
     X = {"vggish": torch.randn(1, 1, n, 128, generator=g), "bert": torch.randn(1, 1, n, 768, generator=g),
          "EXPR_continuous_label": torch.full((1, n, 1), 3.0)}
     tr = Trainer(model, device="cuda", window_length=8, hop_length=5, number_classes=7)
-    perf, per_video = tr.inference([(X, ["clip0"], [n], [np.arange(n)])])
+    perf, per_video = tr.inference([(X, ["clip0"], [n], [np.arange(n)])], keep_logits=True)
     acc = np.zeros((n, 7))
     cnt = np.zeros(n)
     for wd in windowing(np.arange(n), 8, 5):

@@ -36,7 +36,7 @@ def test_windowed_inference_scatter_add_and_average():
     tr = Trainer(_Stub(), device="cpu", window_length=win, hop_length=hop)
     data = {"vggish": torch.arange(n, dtype=torch.float32).view(1, 1, n, 1).repeat(1, 1, 1, 128),
             "video": torch.zeros(1, n, 3, 4, 4)}
-    out = tr.inference_forward_windows(data)
+    out = tr.inference_forward_windows(data, aggregate="host")
     assert tuple(out.shape) == (1, n, 7)
     starts = [0, 200, 350]
     expect = np.zeros((n, 7))
@@ -57,7 +57,7 @@ def test_inference_loop_and_metrics():
             X = {"vggish": torch.ones(1, 1, n, 128), "video": torch.zeros(1, n, 3, 4, 4),
                  "EXPR_continuous_label": torch.full((1, n, 1), float(label))}
             yield X, [f"v{vid}"], [n], [np.arange(n)]
-    perf, per_video = tr.inference(list(loader()))
+    perf, per_video = tr.inference(list(loader()), aggregate="host")
     assert set(per_video) == {"v0", "v1", "v2"} and per_video["v1"]["logits"].shape == (13, ncls)
     # the stub's logits grow with the class index -> every frame predicts the last class (6) == label
     p = perf[None]
