@@ -55,6 +55,7 @@ _SIGNATURES = {
                                   c_int, _P]),
     "cer_bn_apply_nhwc_b3": (c_int, [_P] * 14 + [c_int] * 7 + [_P]),
     "cer_bn_apply_nhwc_n16": (c_int, [_P] * 13 + [c_int] * 8 + [_P]),
+    "cer_fold_bn_3x3": (c_int, [_P, _P, _P, c_int, c_int, _P, _P, _P, c_int, _P, _P]),
     "cer_pack_conv_weight": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cer_weight_norm_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "cer_weight_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),

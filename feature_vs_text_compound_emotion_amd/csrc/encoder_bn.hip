@@ -273,6 +273,62 @@ __global__ __launch_bounds__(256) void bn_apply_n16_kernel(ApplyArgsN16 p) {
     }
 }
 
+// ---- fold a pre-conv BatchNorm (per-input-channel scale s, shift t) into a packed 3x3 weight, one launch per unit ----
+// conv3x3(pad0(s*x + t)) = conv3x3'(pad0(x)) + sum over the taps INSIDE the image of W_tap . t:  w'[o][tap][c] = w * s[c]
+// (written as fp32, as a split hi/lo pair or as one narrow plane) and bias9[3*ry + rx][o] = sum of B[o][tap] over the taps
+// that exist for an output pixel on the first / an inner / the last row (ry) and column (rx), B[o][tap] = sum_c w * t[c].
+// One block per output channel; replaces an einsum + six sums / stacks + pack + split chain of torch launches per unit
+// and training step (ops.fold_input_bn_3x3).
+__global__ __launch_bounds__(256) void fold_bn_3x3_kernel(const float *__restrict__ w, const float *__restrict__ scale,
+                                                          const float *__restrict__ shift, int Cout, int Cin, int Kpad,
+                                                          float *__restrict__ w_f32, uint16_t *__restrict__ w_hi,
+                                                          uint16_t *__restrict__ w_lo, int storage, float *__restrict__ bias9) {
+    __shared__ float red[9][256];
+    const int o = blockIdx.x, tid = threadIdx.x;
+    const float *wr = w + (size_t)o * Kpad;
+    float bt[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) bt[t] = 0.f;
+    for (int c = tid; c < Cin; c += 256) {
+        const float s = scale[c], sh = shift[c];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const size_t k = (size_t)t * Cin + c;
+            const float v = wr[k];
+            bt[t] += v * sh;
+            const float ws = v * s;
+            const size_t idx = (size_t)o * Kpad + k;
+            if (w_f32) w_f32[idx] = ws;
+            if (w_hi) {
+                if (storage) w_hi[idx] = f32_to_n16(ws, storage);
+                else split_bf16(ws, w_hi[idx], w_lo[idx]);
+            }
+        }
+    }
+    for (int k = 9 * Cin + tid; k < Kpad; k += 256) {  // K padding stays zero
+        const size_t idx = (size_t)o * Kpad + k;
+        if (w_f32) w_f32[idx] = 0.f;
+        if (w_hi) { w_hi[idx] = 0; if (!storage) w_lo[idx] = 0; }
+    }
+#pragma unroll
+    for (int t = 0; t < 9; ++t) red[t][tid] = bt[t];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t) red[t][tid] += red[t][tid + s];
+        }
+        __syncthreads();
+    }
+    if (tid < 9) {  // border case 3*ry + rx: rows kh in [ry == 0 ? 1 : 0, ry == 2 ? 1 : 2], same for columns
+        const int ry = tid / 3, rx = tid % 3;
+        float b = 0.f;
+        for (int kh = (ry == 0 ? 1 : 0); kh <= (ry == 2 ? 1 : 2); ++kh)
+            for (int kw = (rx == 0 ? 1 : 0); kw <= (rx == 2 ? 1 : 2); ++kw) b += red[kh * 3 + kw][0];
+        bias9[(size_t)tid * Cout + o] = b;
+    }
+}
+
 }  // namespace cer
 
 using namespace cer;
@@ -367,6 +423,20 @@ extern "C" int cer_bn_apply_nhwc_n16(const float *y, const uint16_t *y16, const 
     ApplyArgsN16 a{y, y16, scale, shift, alpha, res, res_scale, res_shift, mask, res16, out, stats, out16,
                    N * Ho * Wo, Ho, Wo, C, res_stride, Hr, Wr, apply_rows_per_block(N * Ho * Wo), storage};
     CER_LAUNCH(bn_apply_n16_kernel, dim3(cer_bn_apply_stats_tiles(a.P)), dim3(256), 0, (hipStream_t)stream, a);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+extern "C" int cer_fold_bn_3x3(const float *w_packed, const float *scale, const float *shift, int Cout, int Cin, float *w_f32,
+                               uint16_t *w_hi, uint16_t *w_lo, int storage, float *bias9, void *stream) {
+    if (!w_packed || !scale || !shift || !bias9 || Cout <= 0 || Cin <= 0 || (!w_f32 && !w_hi))
+        return cer_set_error(CER_ERR_INVALID_ARG, "fold_bn_3x3: bad argument");
+    if (storage != CER_STORE_NONE && storage != CER_STORE_BF16 && storage != CER_STORE_F16)
+        return cer_set_error(CER_ERR_INVALID_ARG, "fold_bn_3x3: unknown storage");
+    if (w_hi && ((storage == CER_STORE_NONE) != (w_lo != nullptr)))
+        return cer_set_error(CER_ERR_INVALID_ARG, "fold_bn_3x3: split output needs w_hi and w_lo, narrow output w_hi only");
+    CER_LAUNCH(fold_bn_3x3_kernel, dim3(Cout), dim3(256), 0, (hipStream_t)stream, w_packed, scale, shift, Cout, Cin,
+               cer_conv_kpad(3, 3, Cin), w_f32, w_hi, w_lo, storage, bias9);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }

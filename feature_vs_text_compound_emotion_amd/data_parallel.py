@@ -58,17 +58,42 @@ class ClipDataParallel:
             self.broadcast_state()
 
     def broadcast_state(self, src=0):
-        """Replicate rank ``src``'s parameters and buffers (one flat message each)."""
-        for tensors in ([p.data for p in self.model.parameters()],
-                        [b.data for b in self.model.buffers() if b.dtype == torch.float32]):
+        """Replicate rank ``src``'s parameters and buffers (one flat message each).  The copies go through the tensors
+        themselves (not ``.data``), so their version counters move and every packed-weight cache keyed on
+        (data_ptr, _version) -- IR50.pack*, the VGGish / BERT caches -- is rebuilt on the next forward."""
+        for tensors in (list(self.model.parameters()), [b for b in self.model.buffers() if b.dtype == torch.float32]):
             if not tensors:
                 continue
-            flat = torch.cat([t.reshape(-1) for t in tensors])
+            flat = torch.cat([t.detach().reshape(-1) for t in tensors])
             dist.broadcast(flat, src)
             off = 0
-            for t in tensors:
-                t.copy_(flat[off:off + t.numel()].view_as(t))
-                off += t.numel()
+            with torch.no_grad():
+                for t in tensors:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+
+    def sync_buffers(self, mode="mean"):
+        """BatchNorm running statistics are rank-local during training (each rank == the reference on its shard).  Before
+        a checkpoint or an evaluation make them one set again: ``mean`` averages the float buffers over the ranks (every
+        shard's statistics count), ``broadcast`` takes rank 0's.  Integer buffers (num_batches_tracked) are equal already."""
+        if self.world == 1:
+            return
+        bufs = [b for b in self.model.buffers() if b.dtype == torch.float32]
+        if not bufs:
+            return
+        flat = torch.cat([b.detach().reshape(-1) for b in bufs])
+        if mode == "mean":
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat.mul_(1.0 / self.world)
+        elif mode == "broadcast":
+            dist.broadcast(flat, 0)
+        else:
+            raise ValueError(mode)
+        off = 0
+        with torch.no_grad():
+            for b in bufs:
+                b.copy_(flat[off:off + b.numel()].view_as(b))
+                off += b.numel()
 
     def zero_grad(self):
         """Keeps the views alive (``optimizer.zero_grad(set_to_none=True)`` would drop them)."""
@@ -126,6 +151,12 @@ class FlatNesterovSGD:
         ops.sgd_nesterov_flat(self.flat_param, self.ddp.flat, self.buf, g["lr"], g["momentum"], g["dampening"],
                               g["weight_decay"], g["nesterov"], first_step=self.steps == 0)
         self.steps += 1
+        # the kernel wrote through raw pointers: move the version counters like an in-place torch op would, so caches keyed
+        # on (data_ptr, _version) see the update.  Semantics note: every trainable parameter always has a (dense) gradient
+        # view in the bucket, so weight decay and momentum apply to all of them every step -- torch.optim.SGD skips a
+        # parameter whose grad is None after zero_grad(set_to_none=True); the two only differ for a parameter that
+        # receives no gradient at all in a step, which the models here do not have.
+        torch.autograd.graph.increment_version(self.ddp.params)
 
     def state_dict(self):
         return {"momentum_buffer": self.buf, "steps": self.steps, "param_groups": [{k: v for k, v in g.items() if k != "params"}

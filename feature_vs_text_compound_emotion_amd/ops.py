@@ -578,19 +578,40 @@ def bn_apply_nhwc_b3(y, scale, shift, alpha=None, res=None, res_stride=1, res_sc
     return out
 
 
+def fold_bn_3x3_packed(w_packed, scale, shift, out="f32"):
+    """Fold a per-input-channel affine (the BatchNorm in FRONT of a 3x3 / pad 1 / stride 1 conv) into the PACKED weight
+    [Cout, Kpad] in one launch: returns (w * scale[cin] in the requested form, bias9 [9, Cout]).  conv(pad0(s*x + t)) =
+    conv'(pad0(x)) + sum over the taps INSIDE the image of W_tap . t, which only depends on whether the output pixel sits
+    on the first / an inner / the last row and column (9 cases).  ``out``: "f32", "split" (Split) or a narrow torch dtype."""
+    _dev_f32(w_packed, "w_packed")
+    _dev_f32(scale, "scale")
+    _dev_f32(shift, "shift")
+    cout, kpad = w_packed.shape
+    cin = scale.numel()
+    if kpad != conv_kpad(3, 3, cin) or shift.numel() != cin:
+        raise ValueError("fold_bn_3x3_packed: w_packed must be the packing of a [Cout, Cin, 3, 3] weight")
+    b9 = _empty((9, cout), w_packed)
+    wf = hi = lo = None
+    storage = STORE_NONE
+    if out == "f32":
+        res = wf = torch.empty_like(w_packed)
+    elif out == "split":
+        res = Split.empty((cout, kpad), w_packed.device)
+        hi, lo = res.hi, res.lo
+    else:
+        storage = storage_of(out)
+        res = hi = torch.empty((cout, kpad), device=w_packed.device, dtype=out)
+    check(_lib.load().cer_fold_bn_3x3(ptr(w_packed), ptr(scale), ptr(shift), cout, cin, ptr(wf), ptr(hi), ptr(lo), storage,
+                                      ptr(b9), current_stream()), "cer_fold_bn_3x3")
+    return res, b9
+
+
 def fold_input_bn_3x3(w_oihw, scale, shift):
-    """Fold a per-input-channel affine (the batch-statistics BatchNorm in FRONT of a 3x3 / pad 1 / stride 1 conv) into
-    the conv: returns (packed weight of w * scale[cin], bias9 [9, Cout]).  conv(pad0(s*x + t)) = conv'(pad0(x)) +
-    sum over the taps INSIDE the image of W_tap . t, and that sum only depends on whether the output pixel sits on the
-    first / an inner / the last row and column (9 cases).  Weight-sized tensors only (torch ops as plumbing)."""
+    """``fold_bn_3x3_packed`` from the torch-layout weight [Cout, Cin, 3, 3]: (packed fp32 weight, bias9)."""
     _dev_f32(w_oihw, "w")
     if w_oihw.shape[2] != 3 or w_oihw.shape[3] != 3:
         raise ValueError("fold_input_bn_3x3: 3x3 kernels only")
-    wp = pack_conv_weight((w_oihw * scale.view(1, -1, 1, 1)).contiguous())
-    bt = torch.einsum("oikl,i->okl", w_oihw, shift)                    # [Cout, 3, 3]: W_tap . t
-    rows = torch.stack([bt[:, 1:].sum(1), bt.sum(1), bt[:, :2].sum(1)])  # [ry, Cout, kw]: first / inner / last row
-    b9 = torch.stack([rows[:, :, 1:].sum(2), rows.sum(2), rows[:, :, :2].sum(2)], 1)  # [ry, rx, Cout]
-    return wp, b9.reshape(9, -1).contiguous()
+    return fold_bn_3x3_packed(pack_conv_weight(w_oihw.contiguous()), scale.contiguous(), shift.contiguous(), "f32")
 
 
 def gather_rows(src, index):

@@ -194,6 +194,9 @@ class IR50(nn.Module):
         # "bf16" / "fp16": narrow storage -- ONE 16-bit plane per tensor, one MFMA per product, fp32 accumulate and fp32
         # epilogue arithmetic (csrc/conv_n16.hip): what the reference's --amp recipe computes (fp16 autocast,
         # trainer.py:341,367) and BASELINE cfg5's "bf16 storage / fp32 accumulate"
+        # the reference trains under torch.cuda.amp.autocast when --amp is set (trainer.py:341,367): inside an autocast region
+        # the encoder follows it onto the narrow kernels of the autocast dtype (float16 -> "fp16", bfloat16 -> "bf16")
+        self.follow_autocast = True
         self._packed_n16 = None
         self._packed_n16_key = None
         self._packed_train_n16 = None
@@ -339,7 +342,7 @@ class IR50(nn.Module):
             raise RuntimeError("IR50 runs on the HIP kernels only: move the module to a GPU (no CPU fallback)")
         P = {"stem_w": ops.pack_conv_weight(self.input_layer[0].weight.detach().contiguous()), "units": []}
         for u in self.body:
-            d = {"w1": ops.split_bf16(ops.pack_conv_weight(u.res_layer[1].weight.detach().contiguous())),
+            d = {"w1_f32": ops.pack_conv_weight(u.res_layer[1].weight.detach().contiguous()),  # folded per step (batch statistics)
                  "w2": ops.split_bf16(ops.pack_conv_weight(u.res_layer[3].weight.detach().contiguous()))}
             if u.cin != u.depth:
                 d["ws"] = ops.split_bf16(ops.pack_conv_weight(u.shortcut_layer[0].weight.detach().contiguous()))
@@ -459,8 +462,8 @@ class IR50(nn.Module):
                 continue
             last = i + 1 == first_released  # the next consumer (released unit or head) wants fp32
             s1, t1 = self._finalize(xst, ys.numel() // u.cin, u.res_layer[0])
-            w1, b9 = ops.fold_input_bn_3x3(u.res_layer[1].weight.detach(), s1, t1)
-            tt = ops.conv2d_n16(ys, ops.to_n16(w1, dtype), 3, 3, pad=(1, 1), alpha=u.res_layer[2].weight.detach(),
+            w1, b9 = ops.fold_bn_3x3_packed(d["w1_f32"], s1, t1, dtype)
+            tt = ops.conv2d_n16(ys, w1, 3, 3, pad=(1, 1), alpha=u.res_layer[2].weight.detach(),
                                 act1=ops.ACT_PRELU, bias9=b9)["n16"]
             r = ops.conv2d_n16(tt, d["w2"], 3, 3, stride=u.stride, pad=(1, 1), want_stats=True)
             del tt
@@ -546,8 +549,8 @@ class IR50(nn.Module):
                 continue
             last = i + 1 == first_released  # the next consumer (released unit or head) wants fp32
             s1, t1 = self._finalize(xst, ys.hi.numel() // u.cin, u.res_layer[0])
-            w1, b9 = ops.fold_input_bn_3x3(u.res_layer[1].weight.detach(), s1, t1)
-            tt = ops.conv2d_b3(ys, ops.split_bf16(w1), 3, 3, pad=(1, 1), alpha=u.res_layer[2].weight.detach(),
+            w1, b9 = ops.fold_bn_3x3_packed(d["w1_f32"], s1, t1, "split")
+            tt = ops.conv2d_b3(ys, w1, 3, 3, pad=(1, 1), alpha=u.res_layer[2].weight.detach(),
                                act1=ops.ACT_PRELU, bias9=b9)["split"]
             r = ops.conv2d_b3(tt, d["w2"], 3, 3, stride=u.stride, pad=(1, 1), out_f32=True, out_split=False,
                               want_stats=True)
@@ -703,6 +706,12 @@ class IR50(nn.Module):
         if self.precision not in ("bf16x3", "fp32", "bf16", "fp16"):
             raise ValueError(f"unknown precision {self.precision!r}")
         narrow = self.NARROW.get(self.precision)
+        if self.follow_autocast and torch.is_autocast_enabled():
+            narrow = {torch.float16: torch.float16, torch.bfloat16: torch.bfloat16}.get(torch.get_autocast_dtype("cuda"), narrow)
+        with torch.autocast("cuda", enabled=False):   # the kernels take fp32 / explicit narrow tensors: no implicit casts inside
+            return self._forward_impl(x, head_mask, narrow)
+
+    def _forward_impl(self, x, head_mask, narrow):
         if self.training and self.bn_mode == "reference":
             if narrow is not None:
                 return self._forward_batch_stats_n16(x, narrow, head_mask)

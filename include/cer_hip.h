@@ -294,6 +294,13 @@ int cer_bn_apply_nhwc_n16(const float *y, const uint16_t *y16, const float *scal
                           const float *mask, float *out, uint16_t *out16, float *stats, int N, int Ho, int Wo, int C,
                           int res_stride, int Hr, int Wr, int storage, void *stream);
 
+/* Fold the per-input-channel affine (scale, shift) of a BatchNorm in FRONT of a 3x3 / stride 1 / pad 1 conv into the conv
+ * (reference arcface_model.py:53-54: BatchNorm2d -> Conv2d; in model.train() the affine only exists after the batch
+ * reduction): w_packed [Cout][Kpad] (cer_pack_conv_weight) -> w * scale[c] as fp32 (w_f32), split hi/lo (w_hi, w_lo,
+ * storage 0) or one narrow plane (w_hi, storage bf16 / f16), plus bias9 [9][Cout] (see cer_conv_io.bias9).  One launch. */
+int cer_fold_bn_3x3(const float *w_packed, const float *scale, const float *shift, int Cout, int Cin, float *w_f32,
+                    uint16_t *w_hi, uint16_t *w_lo, int storage, float *bias9, void *stream);
+
 /* Nesterov SGD over flat buffers (reference instantiators.py:74-92: torch.optim.SGD(momentum .9, nesterov, wd 1e-4);
  * trainer.py:385-391): d = grad + wd*p; buf = first_step ? d : mu*buf + (1-damp)*d; d = nesterov ? d + mu*buf : buf;
  * p -= lr*d -- torch's _single_tensor_sgd operation by operation, one launch for the whole model.  n % 4 == 0,
