@@ -61,7 +61,7 @@ class VGGish(nn.Module):
                                         nn.Linear(4096, 128))
         self._packed, self._key = None, None
         self._mel = None
-        # "bf16x3": convs 2-6 and the three FCs on the split-bf16 kernels (fp32-class accuracy); "fp32": exact fp32
+        # "bf16x3": convs 2-6 and the three FCs on the split-bf16 kernels (<= 2^-15 relative per product); "fp32": exact fp32
         self.precision = "bf16x3"
 
     def _pack(self):

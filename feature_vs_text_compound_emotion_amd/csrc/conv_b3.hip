@@ -10,20 +10,9 @@
 // One kernel family is shipped: conv_b3_dma16_kernel (LDS-DMA staging, v_mfma_f32_16x16x32_bf16, compact LDS
 // epilogue).  The register-staged, ping-pong, 32x32x16-MFMA, window-resident and 3-stage variants that were measured
 // against it in round 1 (all slower or level) were removed in round 2; they are in the history.
-#include "conv_common.h"
+#include "conv_b3.h"
 
 namespace cer {
-
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));  // 16-byte staging unit (first-class vector:
-                                                                 // HIP's uint4 struct arrays ended up in scratch)
-typedef __attribute__((address_space(3))) void *lds_ptr_t;
-
-__device__ __forceinline__ bf16x8 as_bf16x8(const u32x4 v) { return __builtin_bit_cast(bf16x8, v); }
-
-
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ int swz16(int q) { return (0x78 >> (2 * q)) & 3; }  // F = {0, 2, 3, 1}
 
 // The same kernel on v_mfma_f32_16x16x32_bf16: one MFMA eats the whole 32-deep K step of a 16x16 tile.  Same
 // FLOPs per cycle as 32x32x16, but the chip holds a higher clock on this shape under the power limit that
@@ -386,15 +375,23 @@ static int launch_b3_dma16(const ConvArgs &a, hipStream_t st) {
 }
 
 // tile ids (desc.tile): 0 auto; 41/42/44/45 = 128x128 / 128x64 / 64x128 / 64x64 (4 waves, two LDS stages);
-// 48 = 256x64 (4 waves x (64 pixels x 64 couts)) for Cout <= 64 at large M.
-int conv_b3_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, int &bk) {
+// 48 = 256x64 (4 waves x (64 pixels x 64 couts)) for Cout <= 64 at large M; patch kernels (conv_b3_patch.hip: 3x3 / stride 1 /
+// pad 1 on images with H, W % 16 == 0, the input window of a 16x16 output patch resident in LDS): 51 = 64 couts, 52 = 128 couts.
+static bool b3_patch_geometry(const cer_conv_desc *d) {
+    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil_h == 1 && d->dil_w == 1 && d->pad_t == 1 && d->pad_l == 1 &&
+           d->Ho == d->H && d->Wo == d->W && (d->H & 15) == 0 && (d->W & 15) == 0 && (d->Cin & 31) == 0 && d->split_k <= 1;
+}
+
+int conv_b3_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
+    int tile = d->tile;
+    const long long M = (long long)d->N * d->Ho * d->Wo;
+    const int Cout = d->Cout;
     if (tile == 0) {
-        // measured per layer shape on MI355X (tools/bench_conv.py): with the compact LDS epilogue the
-        // 128x128 tile wins for every Cout >= 128 (also at K = 576 / 1152), 128x64 or (large M) 256x64 serve Cout <= 64,
-        // small grids take 64-row tiles
-        const long long t128 = (M + 127) / 128 * ((Cout + 127) / 128);
-        (void)K;
-        if (Cout <= 64) tile = (M + 255) / 256 >= 512 ? 48 : 42;  // 256x64: 226 vs 204 TF/s on 64->64 @224x224
+        // measured per layer shape on MI355X (tools/bench_conv.py)
+        const long long t128 = (M + 127) / 128 * ((Cout + 127) / 128), t256 = (M + 255) / 256;
+        if (b3_patch_geometry(d) && Cout <= 64 && t256 >= 512) tile = 51;
+        else if (b3_patch_geometry(d) && Cout >= 128 && t256 * ((Cout + 127) / 128) >= 512) tile = 52;
+        else if (Cout <= 64) tile = t256 >= 512 ? 48 : 42;  // 256x64: 226 vs 204 TF/s on 64->64 @224x224
         else if (t128 >= 512) tile = 41;
         else tile = Cout >= 128 ? 44 : 45;
     }
@@ -405,6 +402,8 @@ int conv_b3_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, 
         case 44: bm = 64; bn = 128; break;
         case 45: bm = 64; bn = 64; break;
         case 48: bm = 256; bn = 64; break;
+        case 51: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels
+        case 52: bm = 256; bn = 128; break;
         default: return 0;
     }
     return tile;
@@ -417,6 +416,7 @@ int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 44: return launch_b3_dma16<64, 128, 1, 4>(a, st);
         case 45: return launch_b3_dma16<64, 64, 2, 2>(a, st);
         case 48: return launch_b3_dma16<256, 64, 4, 1>(a, st);
+        case 51: case 52: return conv_b3_patch_launch(tile, a, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3): unknown tile id");
     }
 }
@@ -428,7 +428,7 @@ using namespace cer;
 extern "C" int cer_conv2d_b3_tile(const cer_conv_desc *d) {
     if (!d || d->N <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->Cout <= 0) return 0;
     int bm, bn, bk;
-    return conv_b3_tile_dims(d->tile, d->Cout, (long long)d->N * d->Ho * d->Wo, cer_conv_kpad(d->KH, d->KW, d->Cin), bm, bn, bk);
+    return conv_b3_tile_dims(d, bm, bn, bk);
 }
 
 extern "C" int cer_split_bf16(const float *x, const float *scale, const float *shift, int C, uint16_t *hi, uint16_t *lo,

@@ -1,0 +1,278 @@
+// conv_b3_patch.hip -- the bf16x3 (split hi/lo operand) 3x3 / stride 1 / pad 1 convolution with the INPUT WINDOW RESIDENT
+// IN LDS: the split-operand twin of conv_n16_patch.hip (read that file's header for the why and the PMC evidence).
+//
+//   * a block owns a 16 x 16 patch of output pixels of one image and BN output channels;
+//   * per 32-channel chunk the 18 x 18 input window (halo included, out-of-image pixels = zeros from the range-checked
+//     DMA) is fetched ONCE: two planes (hi, lo) of 324 rows x 64 bytes = 2 x 21 one-KiB LDS-DMA pieces; all nine taps
+//     read their pixel fragments from it at the row shift (r + kh) * 18 + kw.  64-byte rows put four window pixels in a
+//     256-byte bank row; the conflict-free swizzle for fragment rows that start at any alignment is a function of the
+//     window COLUMN found by exhaustive search (tools/check_swizzle.py: B3_PATCH_F);
+//   * the weights stream: one BN x 32 slice (two planes) per (chunk, tap) through a 3-slot ring, two steps ahead, counted
+//     vmcnt; the NEXT chunk's window is fetched a whole chunk (nine steps) ahead into the second window buffer;
+//   * a * b = a_hi * b_hi + a_hi * b_lo + a_lo * b_hi: three v_mfma_f32_16x16x32_bf16 per 16x16 tile and step, 3 * TC per
+//     MFMA group; taps unrolled, fragment reads two groups ahead, DMA pieces between MFMA groups.
+//
+// Against the flat 128-pixel tile this cuts the L2 -> LDS activation traffic of a 3x3 layer from nine fetches of every
+// input line to 1.27 (the halo), the round-1 limiter of the bf16x3 kernel ("both operands' L2 -> LDS
+// traffic"; roofline.traffic 2.2x the algorithmic bytes).
+#include "conv_b3.h"
+
+namespace cer {
+
+// slot = chunk ^ B3_PATCH_F[window column], 2 bits per column (tools/check_swizzle.py)
+constexpr unsigned long long B3_PATCH_F_TABLE = 0xaaa00a00ull;
+__device__ __forceinline__ int b3_patch_f(int wx) { return (int)((B3_PATCH_F_TABLE >> (2 * wx)) & 3ull); }
+
+template <int BN, int WP, int WC>
+__global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs p) {
+    constexpr int NW = WP * WC, NT = NW * 64;
+    constexpr int PH = 16, PWD = 16, WW = 18, WROWS = 18 * 18;
+    constexpr int XPP = (WROWS + 15) / 16;                        // 21 one-KiB pieces (16 rows of 64 bytes) per plane
+    constexpr int XPW = (XPP + NW - 1) / NW;                      // window pieces per wave, plane and chunk
+    constexpr int XPL = XPP * 1024, XBYTES = 2 * XPL;             // plane / buffer bytes
+    constexpr int WPL = BN * 64, WSLICE = 2 * WPL;                // weight plane / slice bytes
+    constexpr int WPIECES = 2 * BN / 16;                          // weight pieces per step (both planes)
+    static_assert(WPIECES % NW == 0, "weight-slice pieces are dealt round-robin to the waves");
+    constexpr int WQ = WPIECES / NW;                              // weight pieces per wave and step
+    constexpr int TP = PH / WP, TC = BN / (16 * WC);
+    static_assert(PH % WP == 0 && XPW <= 9 && TP >= 2, "geometry");
+    constexpr int WOFF = 2 * XBYTES, SINK = WOFF + 3 * WSLICE;    // LDS map: two windows | weight ring | 1 KiB sink
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem_b3p[];
+    unsigned char *smem = reinterpret_cast<unsigned char *>(smem_b3p);
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave % WP, wc = wave / WP;
+    const int kg = lane >> 4, l15 = lane & 15;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {   // XCD-aware remap (bijective)
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % p.tiles_n, patch = bid / p.tiles_n;
+    const int pxn = p.W / PWD, pyn = p.H / PH;
+    const int px = patch % pxn, py = (patch / pxn) % pyn, n = patch / (pxn * pyn);
+    const int c0 = tile_n * BN;
+    const int cin_steps = p.cin_steps;
+
+    // ---- DMA assignment: in a piece lane l owns row l / 4 (16 rows), LDS slot l % 4 ----
+    const int prow = lane >> 2, slot = lane & 3;
+    unsigned x_off[XPW];
+    bool x_real[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int q = wave + NW * i;
+        const int row = q * 16 + prow;
+        const int wy = row / WW, wx = row - wy * WW;
+        const int iy = py * PH - 1 + wy, ix = px * PWD - 1 + wx;
+        const bool inb = q < XPP && row < WROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        x_real[i] = q < XPP;
+        x_off[i] = inb ? (unsigned)(((size_t)iy * p.W + ix) * p.x_ld * 2 + ((slot ^ b3_patch_f(wx)) << 4)) : OOB;
+    }
+    unsigned w_off[WQ];
+    int w_plane[WQ], w_dst[WQ];
+#pragma unroll
+    for (int i = 0; i < WQ; ++i) {
+        const int j = wave + NW * i;                 // piece of the slice: plane j / (BN / 16), 16 rows from (j % (BN / 16)) * 16
+        w_plane[i] = j / (BN / 16);
+        const int row = (j % (BN / 16)) * 16 + prow;
+        w_dst[i] = w_plane[i] * WPL + (j % (BN / 16)) * 1024;
+        w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ swz16((row >> 2) & 3)) << 3)) * 2) : OOB;
+    }
+    const size_t img = (size_t)n * p.H * p.W * p.x_ld * 2;
+    const char *xh = reinterpret_cast<const char *>(p.x_hi) + img, *xl = reinterpret_cast<const char *>(p.x_lo) + img;
+    const size_t wpan = (size_t)c0 * p.Kpad * 2;
+    const char *wh = reinterpret_cast<const char *>(p.w_hi) + wpan, *wl = reinterpret_cast<const char *>(p.w_lo) + wpan;
+
+    // window piece i (both planes) of chunk cc into window buffer cc & 1 -- or two zero pieces into the sink, which keeps
+    // the per-step DMA count of a wave constant (the counted vmcnt relies on it)
+    auto issue_x = [&](int i, int cc) {
+        const bool real = x_real[i] && cc < cin_steps;
+        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xh) + (size_t)cc * 64, 0, (int)OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xl) + (size_t)cc * 64, 0, (int)OOB, 0x00020000);
+        unsigned char *dst = real ? smem + (cc & 1) * XBYTES + (wave + NW * i) * 1024 : smem + SINK;
+        const int vo = (int)(real ? x_off[i] : OOB);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_ptr_t)(real ? dst + XPL : dst), 16, vo, 0, 0, 0);
+    };
+    auto issue_w = [&](int cc, int tap, int ring) {
+        const bool real = cc < cin_steps;
+        const size_t koff = ((size_t)tap * p.Cin + (size_t)cc * 32) * 2;
+#pragma unroll
+        for (int i = 0; i < WQ; ++i) {
+            // (the plane is chosen on the POINTER: a ?: between two buffer resources made hipcc's host pass drop the kernel stub)
+            const char *base = (w_plane[i] ? wl : wh) + koff;
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, (int)OOB, 0x00020000);
+            unsigned char *dst = real ? smem + WOFF + ring * WSLICE + w_dst[i] : smem + SINK;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, (int)(real ? w_off[i] : OOB), 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[TC][TP];
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+
+    // fragment address bases (hi plane; lo plane = + WPL / + XPL)
+    const int arow = WOFF + (wc * TC * 16 + l15) * 64 + ((kg ^ swz16((l15 >> 2) & 3)) << 4);
+    int bcol[3];
+#pragma unroll
+    for (int kw = 0; kw < 3; ++kw) bcol[kw] = (wp * WW + kw + l15) * 64 + ((kg ^ b3_patch_f(kw + l15)) << 4);
+
+    // prologue: the whole window of chunk 0, weight slices of steps 0 and 1
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) issue_x(i, 0);
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+
+    // One step = one filter tap of one 32-channel chunk; per wave and step WQ weight pieces (slice of step s + 2) and, during
+    // taps 0 .. XPW-1, the two planes of one window piece of the next chunk.  At the top of step s everything issued before
+    // step s-1 must have landed: vmcnt(pieces of the previous step).
+    for (int cc = 0; cc < cin_steps; ++cc) {
+        const int xcur = (cc & 1) * XBYTES;
+        static_for<9>([&](auto T) {
+            constexpr int tap = decltype(T)::v, kh = tap / 3, kw = tap % 3;
+            constexpr int ptap = (tap + 8) % 9;
+            constexpr int pcnt = WQ + (ptap < XPW ? 2 : 0);
+            if (cc == 0 && tap == 0) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");  // prologue: all but slice 1
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            constexpr int ntap = (tap + 2) % 9, nring = (tap + 2) % 3;
+            const int ncc = cc + (tap + 2 >= 9 ? 1 : 0);
+            const unsigned char *Wr = smem + (tap % 3) * WSLICE;
+            const unsigned char *Xb = smem + xcur + kh * (WW * 64);
+            // (fragments travel as u32x4 and are re-typed at the MFMA: a lambda returning a __bf16 vector made hipcc's host pass
+            // drop the kernel stub)
+            auto lda = [&](int a, int pl) { return *reinterpret_cast<const u32x4 *>(Wr + pl * WPL + arow + a * 16 * 64); };
+            auto ldb = [&](int b, int pl) { return *reinterpret_cast<const u32x4 *>(Xb + pl * XPL + bcol[kw] + b * WP * WW * 64); };
+            u32x4 ah[TC], al[TC], bh[TP], bl[TP];
+#pragma unroll
+            for (int a = 0; a < TC; ++a) { ah[a] = lda(a, 0); al[a] = lda(a, 1); }
+            bh[0] = ldb(0, 0); bl[0] = ldb(0, 1);
+            bh[1] = ldb(1, 0); bl[1] = ldb(1, 1);
+            static_for<TP>([&](auto G) {
+                constexpr int g = decltype(G)::v;
+                if constexpr (g + 2 < TP) { bh[g + 2] = ldb(g + 2, 0); bl[g + 2] = ldb(g + 2, 1); }
+                if constexpr (g == 0) issue_w(ncc, ntap, nring);
+                if constexpr (g == 1 && tap < XPW) issue_x(tap, cc + 1);
+#pragma unroll
+                for (int a = 0; a < TC; ++a) {
+                    acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
+                    acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bl[g]), acc[a][g], 0, 0, 0);
+                    acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
+                }
+            });
+            // issue order: the 3 * TC MFMAs of group g, then the reads for group g+2 and the group's DMA pieces
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TC + 4, 0);
+            static_for<TP>([&](auto G) {
+                constexpr int g = decltype(G)::v;
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * TC, 0);
+                if constexpr (g + 2 < TP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                constexpr int npiece = (g == 0 ? WQ : 0) + ((g == 1 && tap < XPW) ? 2 : 0);
+                if constexpr (npiece > 0) __builtin_amdgcn_sched_group_barrier(0x010, npiece, 0);
+            });
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sink pieces of the last steps
+
+    // ---- epilogue: accumulators -> LDS (fp32, swizzled granules) -> compact coalesced loop, one patch row per iteration ----
+    constexpr int G = BN / 4, RPI = NT / G;
+    static_assert(NT % G == 0 && RPI % 16 == 0 && 256 * BN * 4 <= SINK, "whole patch rows of 16 pixels per loop iteration; one pass");
+    float *Ct = reinterpret_cast<float *>(smem_b3p);
+    const int g = tid % G, r0 = tid / G, ox = r0 & 15;
+    const int c = c0 + g * 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    static_for<TP>([&](auto B) {
+        constexpr int b = decltype(B)::v;
+        const int ml = (b * WP + wp) * 16 + l15;
+        static_for<TC>([&](auto A) {
+            constexpr int a = decltype(A)::v;
+            const int gg = (wc * TC + a) * 4 + kg;
+            *reinterpret_cast<f32x4 *>(Ct + ml * BN + ((gg ^ (ml & 15)) << 2)) = acc[a][b];
+        });
+    });
+    __syncthreads();
+    const int gx = px * PWD + ox;
+    const int rx = gx == 0 ? 0 : (gx == p.W - 1 ? 2 : 1);
+    const size_t pix0 = ((size_t)n * p.H + (size_t)py * PH) * p.W + gx;
+    for (int oy = r0 >> 4; oy < PH; oy += RPI / 16) {
+        const int ml = oy * 16 + ox;
+        const int m = (int)(pix0 + (size_t)oy * p.W);
+        const f32x4 q = *reinterpret_cast<const f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2));
+        float v[4] = {q[0], q[1], q[2], q[3]};
+        if (c < p.Cout) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s1[t] += v[t];
+                s2[t] += v[t] * v[t];
+            }
+            const float *brow_ = p.bias;
+            if (p.bias9) {
+                const int gy = py * PH + oy;
+                const int ry = gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1);
+                brow_ = p.bias9 + (size_t)(3 * ry + rx) * p.Cout;
+            }
+            epilogue_store4(p, m, c, v, brow_);
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smem_b3p);  // [RPI][2][BN]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            red[(r0 * 2 + 0) * BN + g * 4 + t] = s1[t];
+            red[(r0 * 2 + 1) * BN + g * 4 + t] = s2[t];
+        }
+        __syncthreads();
+        if (tid < BN && c0 + tid < p.Cout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < RPI; ++w) {
+                t1 += red[(w * 2 + 0) * BN + tid];
+                t2 += red[(w * 2 + 1) * BN + tid];
+            }
+            p.stats[((size_t)patch * 2 + 0) * p.Cout + c0 + tid] = t1;
+            p.stats[((size_t)patch * 2 + 1) * p.Cout + c0 + tid] = t2;
+        }
+    }
+}
+
+template <int BN, int WP, int WC>
+static int launch_b3_patch(const ConvArgs &a, hipStream_t st) {
+    const size_t lds = (size_t)2 * 2 * 21 * 1024 + 3 * (size_t)2 * BN * 64 + 1024;
+    auto k = conv_b3_patch_kernel<BN, WP, WC>;
+    if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, 1), dim3(WP * WC * 64), lds, st, a);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+bool conv_b3_patch_ok(const ConvArgs &a) {
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.dil_h != 1 || a.dil_w != 1 || a.pad_t != 1 || a.pad_l != 1 || a.Ho != a.H ||
+        a.Wo != a.W || (a.H & 15) || (a.W & 15) || (a.Cin & 31) || a.split_k != 1)
+        return false;
+    return (long long)a.H * a.W * a.x_ld * 2 < (1ll << 31) && (long long)128 * a.Kpad * 2 < (1ll << 31);
+}
+
+int conv_b3_patch_launch(int tile, const ConvArgs &a, hipStream_t st) {
+    if (!conv_b3_patch_ok(a))
+        return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3, patch kernel): needs a 3x3 / stride 1 / pad 1 conv on images whose "
+                                                   "height and width are multiples of 16, Cin % 32 == 0, no split-K");
+    switch (tile) {
+        case 51: return launch_b3_patch<64, 4, 2>(a, st);
+        case 52: return launch_b3_patch<128, 4, 2>(a, st);
+        default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3, patch kernel): unknown tile id");
+    }
+}
+
+}  // namespace cer

@@ -439,7 +439,7 @@ static int validate_desc(const cer_conv_desc *d) {
 }
 
 namespace cer {
-int conv_b3_tile_dims(int tile, int Cout, long long M, int K, int &bm, int &bn, int &bk);
+int conv_b3_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk);
 int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk);
 }
 
@@ -450,7 +450,7 @@ extern "C" int cer_conv2d_stats_tiles(const cer_conv_desc *d, int kernel_family)
     if (kernel_family == 2) {
         if (!conv_n16_tile_dims(d, bm, bn, bk)) return 0;
     } else if (kernel_family == 1) {
-        const int t = conv_b3_tile_dims(d->tile, d->Cout, M, cer_conv_kpad(d->KH, d->KW, d->Cin), bm, bn, bk);
+        const int t = conv_b3_tile_dims(d, bm, bn, bk);
         if (!t) return 0;
         if (t == 6) return 2 * ((M + bm - 1) / bm);  // the ping-pong kernel writes one row per pixel half-tile
     } else {
@@ -540,7 +540,7 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
             return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow): Cin must be a multiple of 64 and x_ld of 8");
         esz = 2;
     } else if (b3) {
-        tile = conv_b3_tile_dims(d->tile, d->Cout, a.M, a.Kpad, bm, bn, bk);
+        tile = conv_b3_tile_dims(d, bm, bn, bk);
         if (!tile) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3): unknown tile id");
         if (d->Cin % bk != 0 || (a.x_ld & 7))
             return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3): Cin must be a multiple of the K step and x_ld of 8");

@@ -187,9 +187,9 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
 
     // ---- epilogue: accumulators -> LDS (fp32, 16-byte granules XOR-swizzled by the row) -> compact coalesced loop ----
     constexpr int G = BN / 4, RPI = NT / G;
-    static_assert(NT % G == 0 && RPI == 16 && 256 * BN * 4 <= SINK, "one patch row of 16 pixels per loop iteration; one pass");
+    static_assert(NT % G == 0 && RPI % 16 == 0 && 256 * BN * 4 <= SINK, "whole patch rows of 16 pixels per loop iteration; one pass");
     float *Ct = reinterpret_cast<float *>(smem_n16p);
-    const int g = tid % G, ox = tid / G;   // this thread's cout granule and patch column
+    const int g = tid % G, r0 = tid / G, ox = r0 & 15;   // this thread's cout granule, first pixel and patch column
     const int c = c0 + g * 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     __syncthreads();  // the fragment reads of the last step are done
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
     const int gx = px * PWD + ox;
     const int rx = gx == 0 ? 0 : (gx == p.W - 1 ? 2 : 1);
     const size_t pix0 = ((size_t)n * p.H + (size_t)py * PH) * p.W + gx;
-    for (int oy = 0; oy < PH; ++oy) {
+    for (int oy = r0 >> 4; oy < PH; oy += RPI / 16) {
         const int ml = oy * 16 + ox;
         const int m = (int)(pix0 + (size_t)oy * p.W);
         const n_f32x4 q = *reinterpret_cast<const n_f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2));
@@ -231,8 +231,8 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
         float *red = reinterpret_cast<float *>(smem_n16p);  // [RPI][2][BN]
 #pragma unroll
         for (int t = 0; t < 4; ++t) {
-            red[(ox * 2 + 0) * BN + g * 4 + t] = s1[t];
-            red[(ox * 2 + 1) * BN + g * 4 + t] = s2[t];
+            red[(r0 * 2 + 0) * BN + g * 4 + t] = s1[t];
+            red[(r0 * 2 + 1) * BN + g * 4 + t] = s2[t];
         }
         __syncthreads();
         if (tid < BN && c0 + tid < p.Cout) {

@@ -105,8 +105,8 @@ int cer_conv2d_fwd(const cer_conv_desc *d, const float *x, const float *w,
  *
  * bf16x3 mode (x_hi != NULL): operands are SPLIT tensors, value = hi + lo with hi = bf16(v),
  * lo = bf16(v - hi) (two bf16 planes, NHWC / [Cout][Kpad] like the fp32 layouts).  Products are
- * evaluated as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32 accumulation: fp32-class
- * accuracy (|logit error| 1.3e-6 on the full model) at a 5.3x higher matrix ceiling.
+ * evaluated as hi*hi + hi*lo + lo*hi on the bf16 matrix cores with fp32 accumulation: <= 2^-15 relative error per product
+ * (|logit error| 1.3e-6 on the full model) at a 5.3x higher matrix ceiling than the fp32 MFMA path.
  * Outputs (any subset): y fp32; (y_hi, y_lo) split; (y2_hi, y2_lo) = split(out*s2[c]+t2[c]), the next
  * layer's eval-mode pre-conv BatchNorm applied by the producer (the zero padding of the consumer
  * then stays exactly zero).  The residual may be fp32 (`residual`) or split (`res_hi`, `res_lo`).

@@ -31,7 +31,11 @@ def test_split_is_round_to_nearest_and_exact_to_16_bits():
     # 1x1 stride-2 projection shortcut on the big tile (the round-1 case that missed a constant 3e-5 bound by 5 %)
     (4, 64, 256, 9, 1, 2, 41), (7, 256, 512, 5, 1, 2, 41),
     # 256x64 tile (Cout <= 64 at large M)
-    (3, 64, 64, 12, 3, 1, 48), (3, 64, 40, 7, 3, 1, 48), (5, 128, 64, 9, 3, 2, 48), (4, 64, 64, 9, 1, 2, 48)])
+    (3, 64, 64, 12, 3, 1, 48), (3, 64, 40, 7, 3, 1, 48), (5, 128, 64, 9, 3, 2, 48), (4, 64, 64, 9, 1, 2, 48),
+    # patch kernels (input window of a 16x16 output patch resident in LDS): borders on every side, several patches per
+    # image, ragged Cout, 1 / 2 / 4 / 8 channel chunks of 32, two cout tiles per patch
+    (2, 64, 64, 32, 3, 1, 51), (1, 64, 128, 48, 3, 1, 51), (2, 32, 40, 16, 3, 1, 51), (3, 128, 64, 16, 3, 1, 51),
+    (2, 128, 128, 32, 3, 1, 52), (1, 128, 256, 32, 3, 1, 52), (1, 256, 128, 16, 3, 1, 52), (3, 64, 100, 32, 3, 1, 52)])
 def test_conv_b3_matches_fp32(n, cin, cout, hw, k, stride, tile):
     from feature_vs_text_compound_emotion_amd import ops
     x, w = _setup(n, cin, cout, hw, k, n * 100 + cin + cout)
@@ -72,6 +76,36 @@ def test_conv_b3_fused_epilogue_outputs(tile):
     st = r["stats"].cpu().sum(0)
     assert (st[0] - raw.sum((0, 2, 3))).abs().max().item() < 1e-2
     assert (st[1] - (raw * raw).sum((0, 2, 3))).abs().max().item() < 1e-2
+
+
+@pytest.mark.parametrize("cin,cout,tile", [(64, 64, 51), (64, 128, 52), (128, 200, 52), (64, 64, 0), (128, 128, 0)])
+def test_conv_b3_patch_kernel_epilogue_on_non_square_images(cin, cout, tile):
+    """bf16x3 patch kernels: H != W, bias9 (folded input BatchNorm) + PReLU + split residual + statistics; tile 0 on a shape
+    the picker routes to them."""
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(cin + cout)
+    n, h, w = (176, 32, 48) if tile == 0 else (2, 32, 48)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    s1, t1 = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.5
+    alpha = torch.rand(cout, generator=g) * 0.3 + 0.1
+    res = torch.randn(n, cout, h, w, generator=g)
+    raw = F.conv2d((x * s1.view(1, -1, 1, 1)).double(), wt.double(), None, 1, 1)
+    z = F.conv2d((x * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1)).double(), wt.double(), None, 1, 1)
+    ref = torch.where(z >= 0, z, z * alpha.double().view(1, -1, 1, 1)) + res.double()
+    wp, b9 = ops.fold_bn_3x3_packed(ops.pack_conv_weight(wt.cuda()), s1.cuda(), t1.cuda(), "split")
+    xs = ops.split_bf16(x.permute(0, 2, 3, 1).contiguous().cuda())
+    rs = ops.split_bf16(res.permute(0, 2, 3, 1).contiguous().cuda())
+    r = ops.conv2d_b3(xs, wp, 3, 3, pad=(1, 1), alpha=alpha.cuda(), act1=ops.ACT_PRELU, bias9=b9, residual=rs, tile=tile,
+                      out_f32=True, want_stats=True)
+    assert (r["y"].cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item() < 1e-4
+    st = r["stats"].cpu().double().sum(0)
+    npix = float(n * h * w)   # fp32 partial sums over npix values of O(1): relative to the count
+    assert (st[0] - raw.sum((0, 2, 3))).abs().max().item() < 2e-6 * npix + 1e-2
+    assert (st[1] - (raw * raw).sum((0, 2, 3))).abs().max().item() < 2e-6 * npix + 1e-2
+    if tile != 0:
+        with pytest.raises(RuntimeError, match="patch"):
+            ops.conv2d_b3(xs, wp, 3, 3, stride=2, pad=(1, 1), tile=tile)
 
 
 def test_linear_b3_split_k():

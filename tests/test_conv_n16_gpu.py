@@ -108,8 +108,9 @@ def test_conv_n16_patch_kernel_epilogue_on_non_square_images(cin, cout, tile, dt
     assert (r["y"].cpu().permute(0, 3, 1, 2).double() - ref).abs().max().item() < 3e-5
     assert torch.equal(r["n16"].cpu(), r["y"].cpu().to(dtype))
     st = r["stats"].cpu().double().sum(0)
-    assert (st[0] - raw.sum((0, 2, 3))).abs().max().item() < 2e-2
-    assert (st[1] - (raw * raw).sum((0, 2, 3))).abs().max().item() < 2e-2
+    npix = float(n * h * w)   # fp32 partial sums over npix values of O(1): relative to the count
+    assert (st[0] - raw.sum((0, 2, 3))).abs().max().item() < 2e-6 * npix + 1e-2
+    assert (st[1] - (raw * raw).sum((0, 2, 3))).abs().max().item() < 2e-6 * npix + 1e-2
 
 
 def test_conv_n16_patch_kernel_rejects_what_it_cannot_take():

@@ -73,13 +73,18 @@ def test_l2norm_backward_kernel():
     assert (dx.cpu() - x.grad).abs().max().item() < 1e-6
 
 
-@pytest.mark.parametrize("precision,tol", [("fp32", 5e-5), ("bf16x3", 2e-3)])
-def test_released_stage4_matches_reference_step(precision, tol):
+@pytest.mark.parametrize("precision,fixture,tol", [("fp32", "body_release_step.npz", 5e-5), ("fp32", "body_release_step_n32.npz", 5e-5),
+                                                   ("bf16x3", "body_release_step_n32.npz", 1e-3),
+                                                   ("bf16x3", "body_release_step.npz", 2e-3)])
+def test_released_stage4_matches_reference_step(precision, fixture, tol):
     """Second release group (base/parameter_control.py: parameters 163..186 = stage 4, units 21-23) on top of the head:
-    frozen units run on the bf16x3 kernels, released units on the fp32 kernels with their backward."""
+    frozen units run on the bf16x3 kernels, released units on the fp32 kernels with their backward.  Two fixtures from the
+    reference: 6 frames and 32 frames.  On 32 frames (batch statistics over 800 values per stage-4 channel) the bf16x3 path
+    meets north_star's 1e-3 on every gradient element; the 6-frame fixture (150 values per channel) is kept with the 2e-3
+    bound it needs: there the BatchNorm backward of the released units amplifies the frozen units' ~1e-4 feature error."""
     from feature_vs_text_compound_emotion_amd import synth
     from feature_vs_text_compound_emotion_amd.visual_backbone import VisualBackbone
-    g = golden("body_release_step.npz")
+    g = golden(fixture)
     n, hw, wseed, dseed = [int(v) for v in g["meta"]]
     vsd = synth.make_state_dict(synth.visual_backbone_spec("", hw // 8), seed=wseed)
     gen = torch.Generator().manual_seed(dseed)
@@ -112,10 +117,8 @@ def test_released_stage4_matches_reference_step(precision, tol):
         part = got if got.size == ref.size else (got[:8] if "output_layer" in name else got.reshape(-1)[:4096])
         err = np.abs(part.reshape(ref.shape) - ref).max() / max(1.0, np.abs(ref).max())
         worst = max(worst, err)
-        # fp32: everything exact -> 5e-5.  bf16x3: the 21 frozen units carry ~1e-4 on O(1) features (batch statistics over
-        # only 6 frames), which the BatchNorm backward of the released units amplifies -> 1.1e-3 measured on single elements,
-        # gradient norms within 1e-3 (fp32: 1e-4)
         assert err < tol, (name, err)
+    print(f"\n[release] {precision} {fixture}: worst gradient element error (relative to max(1, |ref|)) {worst:.2e}")
     sd = vb.state_dict()
     for k in ("body.21.res_layer.0.running_var", "body.21.shortcut_layer.1.running_mean", "body.23.res_layer.4.running_var",
               "0.running_mean", "4.running_var"):

@@ -97,12 +97,12 @@ def test_jmt_fusion_many_tokens_vs_oracle(mt):
     err_out = (out.detach().cpu().view(bsz, length, 128) - ref.detach()).abs().max().item()
     assert err_out < 1e-5, err_out
     out.backward(go.reshape(bsz * length, 128).cuda())
-    # Gradients: relative L2 error.  A max-norm bound is not meaningful here: with ~10^5 ReLU
-    # pre-activations per layer, one that lands within 1e-7 of zero flips its derivative between
-    # two correct fp32 evaluations (observed: exactly one element at this size, 4e-4 on dv).
+    # Gradients: a BULK bound with an explicit outlier budget instead of a loose max-norm -- a ReLU pre-activation within
+    # rounding of zero flips its derivative between two correct fp32 evaluations, which moves single elements only
     dv = vr.grad.cpu().view(bsz, length, 128).transpose(1, 2)
     da = ar.grad.cpu().view(bsz, length, 64).transpose(1, 2)
-    rel_v = ((dv - v.grad).norm() / v.grad.norm()).item()
-    rel_a = ((da - a.grad).norm() / a.grad.norm()).item()
-    assert rel_v < 2e-3 and rel_a < 2e-3, (rel_v, rel_a)
-    assert (dv - v.grad).abs().max().item() < 5e-3 and (da - a.grad).abs().max().item() < 5e-3
+    outliers = 0
+    for got, want in ((dv, v.grad), (da, a.grad)):
+        outliers += int(((got - want).abs() > (1e-5 + 1e-4 * want.abs())).sum())
+        assert ((got - want).norm() / want.norm()).item() < 2e-4
+    assert outliers <= 4, outliers

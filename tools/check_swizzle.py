@@ -73,6 +73,17 @@ def patch_table_constant():
     return v
 
 
+# conv_b3_patch_kernel: the same window with 64-byte rows (32 bf16 per plane): four rows per bank row, slot = chunk ^
+# B3_PATCH_F[wx] (exhaustive search; the bank-row quarter of a pixel is (2 * wy + wx) & 3).
+B3_PATCH_F = [0, 0, 0, 0, 2, 2, 0, 0, 0, 0, 2, 2, 2, 2, 2, 2, 0, 0]
+
+
+def b3_patch_fragment_addr(lane, out_row, kh, kw):
+    wx = kw + (lane & 15)
+    row = (out_row + kh) * 18 + wx
+    return row * 64 + (((lane >> 4) ^ B3_PATCH_F[wx]) << 4)
+
+
 def main():
     ok = True
     for base in range(0, 256, 16):          # fragment tiles start at multiples of 16 rows
@@ -86,6 +97,9 @@ def main():
     okp = all(worst_way(lambda l: patch_fragment_addr(l, r, kh, kw, kk)) == 1
               for r in range(16) for kh in range(3) for kw in range(3) for kk in (0, 1))
     print("conv_n16 patch-window fragment reads conflict free (all rows, taps):", okp, hex(patch_table_constant()))
+    okq = all(worst_way(lambda l: b3_patch_fragment_addr(l, r, kh, kw)) == 1 for r in range(16) for kh in range(3) for kw in range(3))
+    print("conv_b3 patch-window fragment reads conflict free (all rows, taps):", okq,
+          hex(sum(f << (2 * i) for i, f in enumerate(B3_PATCH_F))))
 
 
 if __name__ == "__main__":
