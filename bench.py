@@ -38,10 +38,13 @@ NARROW = ("bf16", "fp16")
 KERNEL_NAMES = {41: "cer::conv_b3_dma16_kernel<128, 128, 2, 2, 4, 2>", 42: "cer::conv_b3_dma16_kernel<128, 64, 2, 2, 4, 2>",
                 44: "cer::conv_b3_dma16_kernel<64, 128, 1, 4, 4, 2>", 45: "cer::conv_b3_dma16_kernel<64, 64, 2, 2, 4, 2>",
                 48: "cer::conv_b3_dma16_kernel<256, 64, 4, 1, 4, 2>",
-                61: "cer::conv_n16_kernel<256, 256, 2, 4, {f16}>", 62: "cer::conv_n16_kernel<256, 128, 4, 2, {f16}>",
-                63: "cer::conv_n16_kernel<256, 64, 4, 1, {f16}>", 64: "cer::conv_n16_kernel<128, 128, 2, 2, {f16}>",
-                65: "cer::conv_n16_kernel<128, 64, 2, 2, {f16}>", 66: "cer::conv_n16_kernel<64, 64, 2, 2, {f16}>",
-                67: "cer::conv_n16_kernel<64, 128, 1, 4, {f16}>"}
+                51: "cer::conv_b3_patch_kernel<64, 4, 2>", 52: "cer::conv_b3_patch_kernel<128, 4, 2>",
+                71: "cer::conv_n16_patch_kernel<64, 4, 1, 1, {f16}>", 72: "cer::conv_n16_patch_kernel<128, 4, 2, 2, {f16}>",
+                91: "cer::conv_n16_kernel<256, 256, 2, 4, {f16}, 2>", 94: "cer::conv_n16_kernel<128, 128, 2, 2, {f16}, 2>",
+                61: "cer::conv_n16_kernel<256, 256, 2, 4, {f16}, 1>", 62: "cer::conv_n16_kernel<256, 128, 4, 2, {f16}, 1>",
+                63: "cer::conv_n16_kernel<256, 64, 4, 1, {f16}, 1>", 64: "cer::conv_n16_kernel<128, 128, 2, 2, {f16}, 1>",
+                65: "cer::conv_n16_kernel<128, 64, 2, 2, {f16}, 1>", 66: "cer::conv_n16_kernel<64, 64, 2, 2, {f16}, 1>",
+                67: "cer::conv_n16_kernel<64, 128, 1, 4, {f16}, 1>"}
 
 
 def peak_tflops(precision):
@@ -78,7 +81,7 @@ def kernel_source_sha():
     """Identity of the code the traffic profiles were taken on: the conv / BatchNorm kernel sources."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "feature_vs_text_compound_emotion_amd", "csrc")
-    for f in ("conv_common.h", "conv_b3.hip", "conv_n16.hip", "conv_igemm.hip", "encoder_bn.hip"):
+    for f in ("conv_common.h", "conv_b3.hip", "conv_b3_patch.hip", "conv_n16.hip", "conv_n16_patch.hip", "conv_igemm.hip", "encoder_bn.hip"):
         with open(os.path.join(csrc, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
