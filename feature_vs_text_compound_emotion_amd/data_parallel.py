@@ -56,6 +56,10 @@ class ClipDataParallel:
             off += p.numel()
         if broadcast and self.world > 1:
             self.broadcast_state()
+        # independent dropout streams per rank: the models draw their masks from (dropout_seed, counter), and every rank
+        # starts dropout_seed at 0 -- fold the rank in (2^20 steps apart)
+        if self.world > 1 and dist.is_initialized() and hasattr(model, "dropout_seed"):
+            model.dropout_seed += dist.get_rank() << 20
 
     def broadcast_state(self, src=0):
         """Replicate rank ``src``'s parameters and buffers (one flat message each).  The copies go through the tensors

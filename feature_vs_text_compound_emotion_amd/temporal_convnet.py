@@ -163,12 +163,17 @@ class TemporalConvNet(nn.Module):
         if self.training and masks is None and self.dropout > 0:
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
-            masks = []
-            for i, b in enumerate(self.network):
-                n = bsz * length * b.cout
-                masks.append((ops.dropout_mask((bsz * length, b.cout), self.dropout, seed, (2 * i) * n, x_rows.device),
-                              ops.dropout_mask((bsz * length, b.cout), self.dropout, seed, (2 * i + 1) * n,
-                                               x_rows.device)))
+            # all 2 * levels masks from ONE launch over one flat buffer: every mask owns its own counter range of the
+            # (seed, counter) generator -- per-level offsets (2i) * n_i overlapped when the channel count changes between
+            # levels, which made some masks element-for-element copies of others -- and it is 1 launch instead of 8
+            sizes = [bsz * length * b.cout for b in self.network for _ in (0, 1)]
+            flat = ops.dropout_mask((sum(sizes),), self.dropout, seed, 0, x_rows.device)
+            views, off = [], 0
+            for n in sizes:
+                views.append(flat[off:off + n])
+                off += n
+            masks = [(views[2 * i].view(bsz * length, b.cout), views[2 * i + 1].view(bsz * length, b.cout))
+                     for i, b in enumerate(self.network)]
         if not self.training:
             masks = None
         params = [p for b in self.network for p in b.params()]
