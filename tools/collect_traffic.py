@@ -19,7 +19,8 @@ def total(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     s, n = 0.0, 0
     for r in csv.DictReader(open(f)):
-        if ("conv_igemm_kernel" in r["Kernel_Name"] or "conv_b3" in r["Kernel_Name"]) and r["Counter_Name"] == counter:
+        if any(k in r["Kernel_Name"] for k in ("conv_igemm_kernel", "conv_b3", "conv_n16_kernel", "conv_n16_patch")) and \
+                r["Counter_Name"] == counter:
             s += float(r["Counter_Value"])
             n += 1
             k = PER_KERNEL.setdefault(r["Kernel_Name"].split("(")[0].replace("void ", ""), {})
@@ -31,9 +32,14 @@ def total(d, counter):
 def main():
     fetch_dir, write_dir, steps, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
     extra = dict(kv.split("=", 1) for kv in sys.argv[5:])
+    import os
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    sys.modules.setdefault("triton", None)
+    from bench import kernel_source_sha
+    extra["kernel_source_sha"] = kernel_source_sha()   # bench.py reports a profile only for the code it was taken on
     f, nf = total(fetch_dir, "FETCH_SIZE")
     w, nw = total(write_dir, "WRITE_SIZE")
-    res = {"kernel": "cer::conv_b3_dma16_kernel + cer::conv_igemm_kernel (all conv launches of one step)", "steps_profiled": steps,
+    res = {"kernel": "all conv launches of one step (conv_b3_*, conv_n16_*, conv_igemm)", "steps_profiled": steps,
            "launches_per_step": nf / steps,
            "fetch_bytes_per_step": 2.0 * f * 1024 / steps, "write_bytes_per_step": w * 1024 / steps,
            "hbm_bytes_per_step": (2.0 * f + w) * 1024 / steps,
