@@ -1,0 +1,68 @@
+"""CPU-side checks of round-2 host logic: LDS swizzle tables (brute force over the bank model), scores derived from
+confusion counts vs the numpy mirror of the reference's metrics, bench.py helpers."""
+import importlib.util
+import os
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(path, name):
+    spec = importlib.util.spec_from_file_location(name, path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_lds_swizzles_are_conflict_free_under_the_ds_read_b128_bank_model():
+    cs = _load(os.path.join(ROOT, "tools", "check_swizzle.py"), "check_swizzle")
+    for base in range(0, 256, 16):
+        for kk in (0, 1):
+            assert cs.worst_way(lambda l: cs.n16_fragment_addr(l, base, kk)) == 1
+        assert cs.worst_way(lambda l: cs.b3_fragment_addr(l, base)) == 1
+    assert cs.n16_dma_image_is_a_permutation()
+    for r in range(16):
+        for kh in range(3):
+            for kw in range(3):
+                assert cs.worst_way(lambda l: cs.b3_patch_fragment_addr(l, r, kh, kw)) == 1
+                for kk in (0, 1):
+                    assert cs.worst_way(lambda l: cs.patch_fragment_addr(l, r, kh, kw, kk)) == 1
+    # the constants compiled into csrc/conv_n16_patch.hip and csrc/conv_b3_patch.hip
+    assert cs.patch_table_constant() == 0xd92dad912240
+    assert sum(f << (2 * i) for i, f in enumerate(cs.B3_PATCH_F)) == 0xaaa00a00
+    # a linear (unswizzled) image of 128-byte rows is a 4-way conflict: the model does discriminate
+    assert cs.worst_way(lambda l: (l & 15) * 128 + ((l >> 4) << 4)) == 4
+
+
+def test_scores_from_confusion_counts_equal_the_label_list_definitions():
+    from feature_vs_text_compound_emotion_amd import metrics
+    from feature_vs_text_compound_emotion_amd.eval_device import scores_from_confusion
+    rng = np.random.default_rng(3)
+    for n_cls, n in ((7, 500), (8, 40), (7, 3)):
+        trg, prd = rng.integers(0, n_cls - 1, n).tolist(), rng.integers(0, n_cls, n).tolist()  # a class that never is a target
+        cm = np.zeros((n_cls, n_cls), dtype=np.int64)
+        for t, p in zip(trg, prd):
+            cm[t, p] += 1
+        s = scores_from_confusion(cm)
+        f1s, macro = metrics.compute_f1_score(trg, prd, metrics.MACRO_F1)
+        assert np.allclose(s["f1_per_class"], f1s) and abs(s["macro_f1"] - macro) < 1e-12
+        assert abs(s["weighted_f1"] - metrics.compute_f1_score(trg, prd, metrics.W_F1)[1]) < 1e-12
+        assert abs(s["accuracy"] - metrics.compute_class_acc(trg, prd)) < 1e-9
+        assert np.allclose(s["confusion"], metrics.compute_confusion_matrix(trg, prd))
+
+
+def test_bench_helpers():
+    bench = _load(os.path.join(ROOT, "bench.py"), "bench_module")
+    assert bench.peak_tflops("bf16")[0] == 2500.0 and bench.peak_tflops("fp16")[0] == 2500.0
+    assert abs(bench.peak_tflops("bf16x3")[0] - 2500.0 / 3) < 1e-9 and bench.peak_tflops("fp32")[0] == 157.3
+    assert abs(bench.ir50_forward_flops(40) - 6.0545e9) / 6.0545e9 < 1e-3
+    assert abs(bench.ir50_forward_flops(224) - 189.869e9) / 189.869e9 < 1e-3
+    sha = bench.kernel_source_sha()
+    assert len(sha) == 16 and sha == bench.kernel_source_sha()
+    # a committed traffic profile is only reported for the kernel sources it was taken on
+    cfg = {"precision": "bf16x3", "hw": 224, "length": 32, "batch": 32, "encoders": "on"}
+    import json
+    t = json.load(open(os.path.join(ROOT, "profiles", "round2_traffic_bf16x3_hw224_L32.json")))
+    got = bench.measured_traffic(cfg)
+    assert got == (t["hbm_bytes_per_step"] if t["kernel_source_sha"] == sha else None)
