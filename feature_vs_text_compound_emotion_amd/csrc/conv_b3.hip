@@ -376,10 +376,17 @@ static int launch_b3_dma16(const ConvArgs &a, hipStream_t st) {
 
 // tile ids (desc.tile): 0 auto; 41/42/44/45 = 128x128 / 128x64 / 64x128 / 64x64 (4 waves, two LDS stages);
 // 48 = 256x64 (4 waves x (64 pixels x 64 couts)) for Cout <= 64 at large M; patch kernels (conv_b3_patch.hip: 3x3 / stride 1 /
-// pad 1 on images with H, W % 16 == 0, the input window of a 16x16 output patch resident in LDS): 51 = 64 couts, 52 = 128 couts.
+// pad 1 on images with H, W % 16 == 0, the input window of a 16x16 output patch resident in LDS): 51 = 64 couts, 52 = 128 couts;
+// 1-D window kernels (same file: 3x3 / stride 1 / pad 1 at ANY image size with W <= 86, the input window of 256 consecutive
+// output pixels resident in LDS): 53 = 64 couts, 54 = 128 couts.
 static bool b3_patch_geometry(const cer_conv_desc *d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil_h == 1 && d->dil_w == 1 && d->pad_t == 1 && d->pad_l == 1 &&
            d->Ho == d->H && d->Wo == d->W && (d->H & 15) == 0 && (d->W & 15) == 0 && (d->Cin & 31) == 0 && d->split_k <= 1;
+}
+
+static bool b3_win_geometry(const cer_conv_desc *d) {
+    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil_h == 1 && d->dil_w == 1 && d->pad_t == 1 && d->pad_l == 1 &&
+           d->Ho == d->H && d->Wo == d->W && d->H >= 2 && d->W >= 2 && d->W <= 86 && (d->Cin & 31) == 0 && d->split_k <= 1;
 }
 
 int conv_b3_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
@@ -391,6 +398,12 @@ int conv_b3_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         const long long t128 = (M + 127) / 128 * ((Cout + 127) / 128), t256 = (M + 255) / 256;
         if (b3_patch_geometry(d) && Cout <= 64 && t256 >= 512) tile = 51;
         else if (b3_patch_geometry(d) && Cout >= 128 && t256 * ((Cout + 127) / 128) >= 512) tile = 52;
+        else if (b3_win_geometry(d) && d->Cin >= 128 && Cout >= 128 && t256 >= 64) {
+            // one block per CU (the window fills the LDS): whole rounds of 256 blocks; a 128-cout block does twice the work of
+            // a 64-cout block in 1.84x the time (56x56 / 28x28 / 10x10 / 5x5 layers: +17 .. +35 % over the flat 128x128 tile)
+            const long long b54 = t256 * ((Cout + 127) / 128), b53 = t256 * ((Cout + 63) / 64);
+            tile = ((b54 + 255) / 256) * 184 <= ((b53 + 255) / 256) * 100 ? 54 : 53;
+        }
         else if (Cout <= 64) tile = t256 >= 512 ? 48 : 42;  // 256x64: 226 vs 204 TF/s on 64->64 @224x224
         else if (t128 >= 512) tile = 41;
         else tile = Cout >= 128 ? 44 : 45;
@@ -404,6 +417,8 @@ int conv_b3_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         case 48: bm = 256; bn = 64; break;
         case 51: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels
         case 52: bm = 256; bn = 128; break;
+        case 53: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels
+        case 54: bm = 256; bn = 128; break;
         default: return 0;
     }
     return tile;
@@ -416,7 +431,7 @@ int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 44: return launch_b3_dma16<64, 128, 1, 4>(a, st);
         case 45: return launch_b3_dma16<64, 64, 2, 2>(a, st);
         case 48: return launch_b3_dma16<256, 64, 4, 1>(a, st);
-        case 51: case 52: return conv_b3_patch_launch(tile, a, st);
+        case 51: case 52: case 53: case 54: return conv_b3_patch_launch(tile, a, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3): unknown tile id");
     }
 }

@@ -247,6 +247,280 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv_b3_win_kernel: the window-resident structure for ANY image size (3x3 / stride 1 / pad 1): the layers the patch kernel
+// cannot take -- 56x56 and 28x28 at 224x224 input, everything at the reference's 40x40 crop.
+//
+// A block owns 256 CONSECUTIVE flattened output pixels m0 .. m0+255 (they may span image rows and images) and BN couts.  For a
+// stride-1 "same" conv the input of output pixel m under tap (kh, kw) is pixel m + (kh-1)*W + (kw-1) of the same flat
+// [N*H*W] array, so the window is the contiguous pixel range [m0 - W - 1, m0 + 255 + W + 1]: 256 + 2W + 2 rows of 64 bytes per
+// plane, fetched once per 32-channel chunk and double buffered; a tap is a row shift kh*W + kw of the fragment address.
+// Taps that fall off the image (zero padding; the previous / next image row or frame in the flat array) are masked per lane:
+// such a lane reads the window's last row, which the DMA zero-fills.  Fragment rows start at any alignment; the swizzle
+// slot = chunk ^ ((row & 4) >> 1) is conflict free for every alignment (tools/check_swizzle.py).  Everything else -- weight
+// ring, counted vmcnt, unrolled taps, read pipeline, DMA placement -- is the patch kernel's.
+template <int BN, int WP, int WC>
+__global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p, int NP) {
+    constexpr int NW = WP * WC, NT = NW * 64, BM = 256;
+    constexpr int NPMAX = 27;                                     // window pieces (16 rows) per plane the LDS can hold twice
+    constexpr int XPW = (NPMAX + NW - 1) / NW;                    // window pieces per wave, plane and chunk (upper bound)
+    constexpr int WPL = BN * 64, WSLICE = 2 * WPL, WPIECES = 2 * BN / 16;
+    static_assert(WPIECES % NW == 0, "weight-slice pieces are dealt round-robin to the waves");
+    constexpr int WQ = WPIECES / NW;
+    constexpr int TP = BM / (16 * WP), TC = BN / (16 * WC);
+    static_assert(XPW <= 9 && TP >= 2, "geometry");
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem_b3p[];
+    unsigned char *smem = reinterpret_cast<unsigned char *>(smem_b3p);
+    const int XPL = NP * 1024, XBYTES = 2 * XPL, WOFF = 2 * XBYTES, SINK = WOFF + 3 * WSLICE;
+    const int ZROW = NP * 16 - 1;                                 // always zero-filled by the DMA
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave % WP, wc = wave / WP;
+    const int kg = lane >> 4, l15 = lane & 15;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, c0 = tile_n * BN;
+    const int cin_steps = p.cin_steps;
+    const int rows_needed = BM + 2 * p.W + 2;
+    const long long wstart = (long long)m0 - p.W - 1;             // first window pixel (may be negative)
+
+    // ---- DMA assignment ----
+    const int prow = lane >> 2, slot = lane & 3;
+    unsigned x_off[XPW];
+    bool x_real[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int q = wave + NW * i;
+        const int row = q * 16 + prow;
+        const long long pix = wstart + row;
+        const bool inb = q < NP && row < rows_needed && pix >= 0 && pix < (long long)p.M;
+        x_real[i] = q < NP;
+        x_off[i] = inb ? (unsigned)(((size_t)row * p.x_ld + ((slot ^ ((row & 4) >> 1)) << 3)) * 2) : OOB;
+    }
+    unsigned w_off[WQ];
+    int w_plane[WQ], w_dst[WQ];
+#pragma unroll
+    for (int i = 0; i < WQ; ++i) {
+        const int j = wave + NW * i;
+        w_plane[i] = j / (BN / 16);
+        const int row = (j % (BN / 16)) * 16 + prow;
+        w_dst[i] = w_plane[i] * WPL + (j % (BN / 16)) * 1024;
+        w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ swz16((row >> 2) & 3)) << 3)) * 2) : OOB;
+    }
+    // 64-bit base of the window's first pixel (never dereferenced where it points outside the tensor: those lanes are OOB)
+    const long long wbase = wstart * (long long)p.x_ld * 2;
+    const char *xh = reinterpret_cast<const char *>(p.x_hi) + wbase, *xl = reinterpret_cast<const char *>(p.x_lo) + wbase;
+    const size_t wpan = (size_t)c0 * p.Kpad * 2;
+    const char *wh = reinterpret_cast<const char *>(p.w_hi) + wpan, *wl = reinterpret_cast<const char *>(p.w_lo) + wpan;
+
+    auto issue_x = [&](int i, int cc) {
+        const bool real = x_real[i] && cc < cin_steps;
+        const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xh) + (size_t)cc * 64, 0, (int)OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xl) + (size_t)cc * 64, 0, (int)OOB, 0x00020000);
+        unsigned char *dst = real ? smem + (cc & 1) * XBYTES + (wave + NW * i) * 1024 : smem + SINK;
+        const int vo = (int)(real ? x_off[i] : OOB);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_ptr_t)(real ? dst + XPL : dst), 16, vo, 0, 0, 0);
+    };
+    auto issue_w = [&](int cc, int tap, int ring) {
+        const bool real = cc < cin_steps;
+        const size_t koff = ((size_t)tap * p.Cin + (size_t)cc * 32) * 2;
+#pragma unroll
+        for (int i = 0; i < WQ; ++i) {
+            const char *base = (w_plane[i] ? wl : wh) + koff;
+            const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(base), 0, (int)OOB, 0x00020000);
+            unsigned char *dst = real ? smem + WOFF + ring * WSLICE + w_dst[i] : smem + SINK;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_ptr_t)dst, 16, (int)(real ? w_off[i] : OOB), 0, 0, 0);
+        }
+    };
+
+    f32x4 acc[TC][TP];
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+
+    // per pixel tile (t = b * WP + wp): the lane's window row under tap (0,0) and the 9-bit mask of the taps inside its image
+    int prow0[TP];
+    unsigned taps[TP];
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+        const int pl = (b * WP + wp) * 16 + l15;
+        prow0[b] = pl;
+        const int m = m0 + pl;
+        unsigned bits = 0;
+        if (m < p.M) {
+            const int r = m % (p.H * p.W);
+            const int y = r / p.W, x = r - y * p.W;
+            int t = 0;
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw, ++t)
+                    if ((unsigned)(y + kh - 1) < (unsigned)p.H && (unsigned)(x + kw - 1) < (unsigned)p.W) bits |= 1u << t;
+        }
+        taps[b] = bits;
+    }
+    const int arow = (wc * TC * 16 + l15) * 64 + ((kg ^ swz16((l15 >> 2) & 3)) << 4);
+
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) issue_x(i, 0);
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+
+    for (int cc = 0; cc < cin_steps; ++cc) {
+        const int xcur = (cc & 1) * XBYTES;
+        static_for<9>([&](auto T) {
+            constexpr int tap = decltype(T)::v, kh = tap / 3, kw = tap % 3;
+            constexpr int ptap = (tap + 8) % 9;
+            constexpr int pcnt = WQ + (ptap < XPW ? 2 : 0);
+            if (cc == 0 && tap == 0) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            constexpr int ntap = (tap + 2) % 9, nring = (tap + 2) % 3;
+            const int ncc = cc + (tap + 2 >= 9 ? 1 : 0);
+            const unsigned char *Wr = smem + WOFF + (tap % 3) * WSLICE;
+            const unsigned char *Xb = smem + xcur;
+            const int toff = kh * p.W + kw;
+            auto lda = [&](int a, int pl) { return *reinterpret_cast<const u32x4 *>(Wr + pl * WPL + arow + a * 16 * 64); };
+            int baddr[TP];
+#pragma unroll
+            for (int b = 0; b < TP; ++b) {
+                const int row = ((taps[b] >> tap) & 1u) ? prow0[b] + toff : ZROW;
+                baddr[b] = row * 64 + ((kg ^ ((row & 4) >> 1)) << 4);
+            }
+            auto ldb = [&](int b, int pl) { return *reinterpret_cast<const u32x4 *>(Xb + pl * XPL + baddr[b]); };
+            u32x4 ah[TC], al[TC], bh[TP], bl[TP];
+#pragma unroll
+            for (int a = 0; a < TC; ++a) { ah[a] = lda(a, 0); al[a] = lda(a, 1); }
+            bh[0] = ldb(0, 0); bl[0] = ldb(0, 1);
+            bh[1] = ldb(1, 0); bl[1] = ldb(1, 1);
+            static_for<TP>([&](auto G) {
+                constexpr int g = decltype(G)::v;
+                if constexpr (g + 2 < TP) { bh[g + 2] = ldb(g + 2, 0); bl[g + 2] = ldb(g + 2, 1); }
+                if constexpr (g == 0) issue_w(ncc, ntap, nring);
+                if constexpr (g == 1 && tap < XPW) issue_x(tap, cc + 1);
+#pragma unroll
+                for (int a = 0; a < TC; ++a) {
+                    acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
+                    acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bl[g]), acc[a][g], 0, 0, 0);
+                    acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
+                }
+            });
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TC + 4, 0);
+            static_for<TP>([&](auto G) {
+                constexpr int g = decltype(G)::v;
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * TC, 0);
+                if constexpr (g + 2 < TP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                constexpr int npiece = (g == 0 ? WQ : 0) + ((g == 1 && tap < XPW) ? 2 : 0);
+                if constexpr (npiece > 0) __builtin_amdgcn_sched_group_barrier(0x010, npiece, 0);
+            });
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: accumulators -> LDS (fp32, swizzled granules) -> compact coalesced loop over consecutive output rows ----
+    constexpr int G = BN / 4, RPI = NT / G;
+    static_assert(NT % G == 0, "one thread per granule");
+    float *Ct = reinterpret_cast<float *>(smem_b3p);   // the launcher sizes the LDS for 256 * BN floats at least
+    const int g = tid % G, r0 = tid / G;
+    const int c = c0 + g * 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    static_for<TP>([&](auto B) {
+        constexpr int b = decltype(B)::v;
+        const int ml = (b * WP + wp) * 16 + l15;
+        static_for<TC>([&](auto A) {
+            constexpr int a = decltype(A)::v;
+            const int gg = (wc * TC + a) * 4 + kg;
+            *reinterpret_cast<f32x4 *>(Ct + ml * BN + ((gg ^ (ml & 15)) << 2)) = acc[a][b];
+        });
+    });
+    __syncthreads();
+    int ho = 0, wo = 0;
+    if (p.bias9) {
+        const int mm = m0 + r0 < p.M ? m0 + r0 : 0;
+        const int r = mm % (p.Ho * p.Wo);
+        ho = r / p.Wo;
+        wo = r - ho * p.Wo;
+    }
+    for (int ml = r0; ml < BM; ml += RPI) {
+        const int m = m0 + ml;
+        if (m >= p.M) break;
+        const f32x4 q = *reinterpret_cast<const f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2));
+        float v[4] = {q[0], q[1], q[2], q[3]};
+        if (c < p.Cout) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s1[t] += v[t];
+                s2[t] += v[t] * v[t];
+            }
+            const float *brow_ = p.bias;
+            if (p.bias9) {
+                const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
+                brow_ = p.bias9 + (size_t)(3 * ry + rx) * p.Cout;
+            }
+            epilogue_store4(p, m, c, v, brow_);
+        }
+        if (p.bias9) {
+            wo += RPI;
+            while (wo >= p.Wo) {
+                wo -= p.Wo;
+                if (++ho == p.Ho) ho = 0;
+            }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smem_b3p);  // [RPI][2][BN]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            red[(r0 * 2 + 0) * BN + g * 4 + t] = s1[t];
+            red[(r0 * 2 + 1) * BN + g * 4 + t] = s2[t];
+        }
+        __syncthreads();
+        if (tid < BN && c0 + tid < p.Cout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < RPI; ++w) {
+                t1 += red[(w * 2 + 0) * BN + tid];
+                t2 += red[(w * 2 + 1) * BN + tid];
+            }
+            p.stats[((size_t)tile_m * 2 + 0) * p.Cout + c0 + tid] = t1;
+            p.stats[((size_t)tile_m * 2 + 1) * p.Cout + c0 + tid] = t2;
+        }
+    }
+}
+
+// window pieces per plane for this conv, or 0 when the window does not fit twice beside the weight ring
+static int b3_win_pieces(const ConvArgs &a) {
+    const int np = (256 + 2 * a.W + 2 + 1 + 15) / 16;   // + 1: the last row stays zero (masked taps read it)
+    return np <= 27 ? np : 0;                           // 4 * 27 KiB + the 48 KiB weight ring + sink <= 160 KiB: W <= 86
+}
+
+template <int BN, int WP, int WC>
+static int launch_b3_win(const ConvArgs &a, hipStream_t st) {
+    const int np = b3_win_pieces(a);
+    size_t lds = (size_t)4 * np * 1024 + 3 * (size_t)2 * BN * 64 + 1024;
+    if (lds < (size_t)256 * BN * 4) lds = (size_t)256 * BN * 4;   // the epilogue's accumulator tile
+    auto k = conv_b3_win_kernel<BN, WP, WC>;
+    if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, 1), dim3(WP * WC * 64), lds, st, a, np);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
 template <int BN, int WP, int WC>
 static int launch_b3_patch(const ConvArgs &a, hipStream_t st) {
     const size_t lds = (size_t)2 * 2 * 21 * 1024 + 3 * (size_t)2 * BN * 64 + 1024;
@@ -264,7 +538,20 @@ bool conv_b3_patch_ok(const ConvArgs &a) {
     return (long long)a.H * a.W * a.x_ld * 2 < (1ll << 31) && (long long)128 * a.Kpad * 2 < (1ll << 31);
 }
 
+bool conv_b3_win_ok(const ConvArgs &a) {
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.dil_h != 1 || a.dil_w != 1 || a.pad_t != 1 || a.pad_l != 1 || a.Ho != a.H ||
+        a.Wo != a.W || a.H < 2 || a.W < 2 || (a.Cin & 31) || a.split_k != 1 || b3_win_pieces(a) == 0)
+        return false;
+    return (long long)(512 + 2 * a.W) * a.x_ld * 2 < (1ll << 31) && (long long)128 * a.Kpad * 2 < (1ll << 31);
+}
+
 int conv_b3_patch_launch(int tile, const ConvArgs &a, hipStream_t st) {
+    if (tile == 53 || tile == 54) {
+        if (!conv_b3_win_ok(a))
+            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3, window kernel): needs a 3x3 / stride 1 / pad 1 conv with W <= 86, "
+                                                       "Cin % 32 == 0, no split-K");
+        return tile == 53 ? launch_b3_win<64, 4, 2>(a, st) : launch_b3_win<128, 4, 2>(a, st);
+    }
     if (!conv_b3_patch_ok(a))
         return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3, patch kernel): needs a 3x3 / stride 1 / pad 1 conv on images whose "
                                                    "height and width are multiples of 16, Cin % 32 == 0, no split-K");

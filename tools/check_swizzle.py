@@ -84,6 +84,20 @@ def b3_patch_fragment_addr(lane, out_row, kh, kw):
     return row * 64 + (((lane >> 4) ^ B3_PATCH_F[wx]) << 4)
 
 
+# conv_b3_win_kernel / conv_n16_win_kernel: a contiguous (1-D) window of flattened pixels; a fragment is 16 consecutive window
+# rows starting at ANY row (tap shift (kh-1) * W + (kw-1) for arbitrary W).  Exact search (pairwise-constraint DFS over
+# period-16 tables) shows that one table serves every alignment: 64-byte rows slot = chunk ^ ((row & 4) >> 1), 128-byte rows
+# slot = chunk ^ (row & 6).
+def b3_win_fragment_addr(lane, first_row):
+    row = first_row + (lane & 15)
+    return row * 64 + (((lane >> 4) ^ ((row & 4) >> 1)) << 4)
+
+
+def n16_win_fragment_addr(lane, first_row, kk):
+    row = first_row + (lane & 15)
+    return row * 128 + ((((lane >> 4) + 4 * kk) ^ (row & 6)) << 4)
+
+
 def main():
     ok = True
     for base in range(0, 256, 16):          # fragment tiles start at multiples of 16 rows
@@ -97,6 +111,9 @@ def main():
     okp = all(worst_way(lambda l: patch_fragment_addr(l, r, kh, kw, kk)) == 1
               for r in range(16) for kh in range(3) for kw in range(3) for kk in (0, 1))
     print("conv_n16 patch-window fragment reads conflict free (all rows, taps):", okp, hex(patch_table_constant()))
+    okw = all(worst_way(lambda l: b3_win_fragment_addr(l, r)) == 1 for r in range(64)) and \
+        all(worst_way(lambda l: n16_win_fragment_addr(l, r, kk)) == 1 for r in range(64) for kk in (0, 1))
+    print("1-D window fragment reads conflict free at every alignment (b3 and n16):", okw)
     okq = all(worst_way(lambda l: b3_patch_fragment_addr(l, r, kh, kw)) == 1 for r in range(16) for kh in range(3) for kw in range(3))
     print("conv_b3 patch-window fragment reads conflict free (all rows, taps):", okq,
           hex(sum(f << (2 * i) for i, f in enumerate(B3_PATCH_F))))
