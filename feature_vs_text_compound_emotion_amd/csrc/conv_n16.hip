@@ -362,10 +362,16 @@ static int launch_n16(const ConvArgs &a, hipStream_t st) {
 // tile ids (desc.tile): 0 = auto; flat kernels: 61 = 256x256 (8 waves), 62 = 256x128 (8 waves), 63 = 256x64 (4 waves),
 // 64 = 128x128, 65 = 128x64, 66 = 64x64, 67 = 64x128 (4 waves each), K step 64; 81-84 / 91, 94 = A/B variants of the DMA
 // placement; patch kernels (conv_n16_patch.hip, 3x3 / stride 1 / pad 1 on images with H, W % 16 == 0): 71 = 16x16 pixels x
-// 64 couts (Cin == 64), 72 = 16x16 pixels x 128 couts.
+// 64 couts (Cin == 64), 72 = 16x16 pixels x 128 couts; 1-D window kernels (same file, 3x3 / stride 1 / pad 1 at ANY image size
+// with W <= 86: the window of 256 consecutive output pixels resident in LDS): 73 = 64 couts, 74 = 128 couts.
 static bool patch_geometry(const cer_conv_desc *d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil_h == 1 && d->dil_w == 1 && d->pad_t == 1 && d->pad_l == 1 &&
            d->Ho == d->H && d->Wo == d->W && (d->H & 15) == 0 && (d->W & 15) == 0 && (d->Cin & 63) == 0 && d->split_k <= 1;
+}
+
+static bool win_geometry(const cer_conv_desc *d) {
+    return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil_h == 1 && d->dil_w == 1 && d->pad_t == 1 && d->pad_l == 1 &&
+           d->Ho == d->H && d->Wo == d->W && d->H >= 2 && d->W >= 2 && d->W <= 86 && (d->Cin & 63) == 0 && d->split_k <= 1;
 }
 
 int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
@@ -376,6 +382,12 @@ int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         const long long t256 = (M + 255) / 256;
         if (patch_geometry(d) && d->Cin == 64 && t256 * ((Cout + 63) / 64) >= 1024) tile = 71;
         else if (patch_geometry(d) && Cout >= 128 && t256 * ((Cout + 127) / 128) >= 512) tile = 72;
+        else if (win_geometry(d) && t256 >= 64) {
+            // one block per CU (the windows fill the LDS): whole rounds of 256 blocks; a 128-cout block does twice the work of
+            // a 64-cout block in 1.68x the time (fp16, 1024 frames: 56x56 875 -> 957, 28x28 1066 -> 1158, 5x5 720 -> 939 TF/s)
+            const long long b74 = t256 * ((Cout + 127) / 128), b73 = t256 * ((Cout + 63) / 64);
+            tile = Cout > 64 && ((b74 + 255) / 256) * 168 <= ((b73 + 255) / 256) * 100 ? 74 : 73;
+        }
         else if (Cout <= 64) tile = t256 >= 512 ? 63 : ((M + 127) / 128 >= 256 ? 65 : 66);
         else if (Cout <= 128) tile = (M + 127) / 128 >= 256 ? 64 : 67;
         else if (t256 * ((Cout + 255) / 256) >= 512) tile = 91;
@@ -393,6 +405,8 @@ int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         case 67: bm = 64; bn = 128; break;
         case 71: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels
         case 72: bm = 256; bn = 128; break;
+        case 73: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels
+        case 74: bm = 256; bn = 128; break;
         default: return 0;
     }
     return tile;
@@ -407,7 +421,7 @@ int conv_n16_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 65: return launch_n16<128, 64, 2, 2>(a, st);
         case 66: return launch_n16<64, 64, 2, 2>(a, st);
         case 67: return launch_n16<64, 128, 1, 4>(a, st);
-        case 71: case 72: return conv_n16_patch_launch(tile, a, st);
+        case 71: case 72: case 73: case 74: return conv_n16_patch_launch(tile, a, st);
         case 81: return launch_n16<256, 256, 2, 4, 0>(a, st);
         case 82: return launch_n16<256, 128, 4, 2, 0>(a, st);
         case 83: return launch_n16<256, 64, 4, 1, 0>(a, st);

@@ -248,6 +248,282 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
     }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// conv_n16_win_kernel: the window-resident structure for ANY image size (3x3 / stride 1 / pad 1) -- the 56x56 / 28x28 / 14x14 /
+// 7x7 layers of the 224x224 pyramid and everything at the reference's 40x40 crop, which the 16x16-patch kernel cannot take.
+// A block owns 256 CONSECUTIVE flattened output pixels m0 .. m0+255 (they may span image rows and images) and BN couts; the
+// input of pixel m under tap (kh, kw) is pixel m + (kh-1) W + (kw-1) of the same flat array, so the window is the contiguous
+// range [m0 - W - 1, m0 + 256 + W]: 258 + 2W rows of 128 bytes, fetched once per 64-channel chunk into one of two buffers; a
+// tap is a row shift kh W + kw of the fragment address.  Taps outside the image (zero padding; in the flat array they are the
+// neighbouring image row / frame) are masked per lane: the lane reads the window's last row, which the DMA zero-fills.
+// Fragment rows start at any alignment: slot = chunk ^ (row & 6) is conflict free for all of them (tools/check_swizzle.py).
+template <int BN, int WP, int WC, bool F16>
+__global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs p, int NP) {
+    constexpr int NW = WP * WC, NT = NW * 64, BM = 256;
+    constexpr int NPMAX = 54;                                       // 8-row window pieces per buffer the LDS can hold twice (W <= 86)
+    constexpr int XPW = (NPMAX + NW - 1) / NW;
+    constexpr int WSLICE = BN * 128, RING = 3;
+    static_assert(BN % (8 * NW) == 0, "weight-slice pieces are dealt round-robin to the waves");
+    constexpr int WQ = BN / (8 * NW);
+    constexpr int TP = BM / (16 * WP), TC = BN / (16 * WC);
+    static_assert(XPW <= 9 && TP >= 2, "geometry");
+    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NGRP = 2 * TP;
+    extern __shared__ __attribute__((aligned(16))) uint16_t smem_n16p[];
+    unsigned char *smem = reinterpret_cast<unsigned char *>(smem_n16p);
+    const int XBYTES = NP * 1024, WOFF = 2 * XBYTES, SINK = WOFF + RING * WSLICE;
+    const int ZROW = NP * 8 - 1;                                    // past the rows the taps address: always zero-filled
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wp = wave % WP, wc = wave / WP;
+    const int kg = lane >> 4, l15 = lane & 15;
+
+    const int nwg = p.tiles_m * p.tiles_n;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int m0 = tile_m * BM, c0 = tile_n * BN;
+    const int cin_steps = p.cin_steps;
+    const int rows_needed = BM + 2 * p.W + 2;
+    const long long wstart = (long long)m0 - p.W - 1;               // first window pixel (negative in the first tile)
+
+    const int prow = lane >> 3, slot = lane & 7;
+    unsigned x_off[XPW];
+    bool x_real[XPW];
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) {
+        const int q = wave + NW * i;
+        const int row = q * 8 + prow;
+        const long long pix = wstart + row;
+        const bool inb = q < NP && row < rows_needed && pix >= 0 && pix < (long long)p.M;
+        x_real[i] = q < NP;
+        x_off[i] = inb ? (unsigned)(((size_t)row * p.x_ld + ((slot ^ (row & 6)) << 3)) * 2) : OOB;
+    }
+    unsigned w_off[WQ];
+#pragma unroll
+    for (int i = 0; i < WQ; ++i) {
+        const int row = (wave + NW * i) * 8 + prow;
+        w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ ((row >> 1) & 7)) << 3)) * 2) : OOB;
+    }
+    // base of the window's first pixel; lanes whose pixel lies outside the tensor carry the out-of-range offset instead
+    const char *xwin = reinterpret_cast<const char *>(p.x_hi) + wstart * (long long)p.x_ld * 2;
+    const char *wpanel = reinterpret_cast<const char *>(p.w_hi) + (size_t)c0 * p.Kpad * 2;
+
+    auto issue_x = [&](int i, int cc) {
+        const bool real = x_real[i] && cc < cin_steps;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xwin) + (size_t)cc * 128, 0, (int)OOB, 0x00020000);
+        unsigned char *dst = real ? smem + (cc & 1) * XBYTES + (wave + NW * i) * 1024 : smem + SINK;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (n_lds_ptr_t)dst, 16, (int)(real ? x_off[i] : OOB), 0, 0, 0);
+    };
+    auto issue_w = [&](int cc, int tap, int ring) {
+        const bool real = cc < cin_steps;
+        const __amdgpu_buffer_rsrc_t rw = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<char *>(wpanel) + ((size_t)tap * p.Cin + (size_t)cc * 64) * 2, 0, (int)OOB, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < WQ; ++i) {
+            unsigned char *dst = real ? smem + WOFF + ring * WSLICE + (wave + NW * i) * 1024 : smem + SINK;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (n_lds_ptr_t)dst, 16, (int)(real ? w_off[i] : OOB), 0, 0, 0);
+        }
+    };
+
+    n_f32x4 acc[TC][TP];
+#pragma unroll
+    for (int a = 0; a < TC; ++a)
+#pragma unroll
+        for (int b = 0; b < TP; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+
+    // per pixel tile b: the lane's window row under tap (0, 0) and the 9-bit mask of the taps that stay inside its image
+    int prow0[TP];
+    unsigned taps[TP];
+#pragma unroll
+    for (int b = 0; b < TP; ++b) {
+        const int pl = (b * WP + wp) * 16 + l15;
+        prow0[b] = pl;
+        const int m = m0 + pl;
+        unsigned bits = 0;
+        if (m < p.M) {
+            const int r = m % (p.H * p.W);
+            const int y = r / p.W, x = r - y * p.W;
+            int t = 0;
+            for (int kh = 0; kh < 3; ++kh)
+                for (int kw = 0; kw < 3; ++kw, ++t)
+                    if ((unsigned)(y + kh - 1) < (unsigned)p.H && (unsigned)(x + kw - 1) < (unsigned)p.W) bits |= 1u << t;
+        }
+        taps[b] = bits;
+    }
+    const int arow = (wc * TC * 16 + l15) * 128 + ((kg ^ ((l15 >> 1) & 7)) << 4);
+
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) issue_x(i, 0);
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+
+    for (int cc = 0; cc < cin_steps; ++cc) {
+        const int xcur = (cc & 1) * XBYTES;
+        static_for<9>([&](auto T) {
+            constexpr int tap = decltype(T)::v, kh = tap / 3, kw = tap % 3;
+            constexpr int ptap = (tap + 8) % 9;
+            constexpr int pcnt = WQ + (ptap < XPW ? 1 : 0);
+            if (cc == 0 && tap == 0) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();
+            constexpr int ntap = (tap + 2) % 9, nring = (tap + 2) % 3;
+            const int ncc = cc + (tap + 2 >= 9 ? 1 : 0);
+            const unsigned char *Wr = smem + WOFF + (tap % 3) * WSLICE;
+            const unsigned char *Xb = smem + xcur;
+            const int toff = kh * p.W + kw;
+            int baddr[TP];
+#pragma unroll
+            for (int b = 0; b < TP; ++b) {
+                const int row = ((taps[b] >> tap) & 1u) ? prow0[b] + toff : ZROW;
+                baddr[b] = row * 128 + ((kg ^ (row & 6)) << 4);
+            }
+            auto lda = [&](int a, int kk) { return *reinterpret_cast<const n_u32x4 *>(Wr + ((arow + a * 16 * 128) ^ (kk << 6))); };
+            auto ldb = [&](int b, int kk) { return *reinterpret_cast<const n_u32x4 *>(Xb + (baddr[b] ^ (kk << 6))); };
+            n_u32x4 af[2][TC], bf[NGRP];
+#pragma unroll
+            for (int a = 0; a < TC; ++a) af[0][a] = lda(a, 0);
+            bf[0] = ldb(0, 0);
+            bf[1] = ldb(1 % TP, 1 / TP);
+            static_for<NGRP>([&](auto G) {
+                constexpr int g = decltype(G)::v, kk = g / TP, b = g % TP;
+                if constexpr (g + 2 < NGRP) bf[g + 2] = ldb((g + 2) % TP, (g + 2) / TP);
+                if constexpr (g == 0) {
+#pragma unroll
+                    for (int a = 0; a < TC; ++a) af[1][a] = lda(a, 1);
+                }
+                if constexpr (g == 0) issue_w(ncc, ntap, nring);
+                if constexpr (g == 2 % NGRP && tap < XPW) issue_x(tap, cc + 1);
+#pragma unroll
+                for (int a = 0; a < TC; ++a) acc[a][b] = mfma_n16<F16>(af[kk][a], bf[g], acc[a][b]);
+            });
+            __builtin_amdgcn_sched_group_barrier(0x100, TC + 2, 0);
+            static_for<NGRP>([&](auto G) {
+                constexpr int g = decltype(G)::v;
+                __builtin_amdgcn_sched_group_barrier(0x008, TC, 0);
+                constexpr int nread = (g + 2 < NGRP ? 1 : 0) + (g == 0 ? TC : 0);
+                if constexpr (nread > 0) __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);
+                constexpr int npiece = (g == 0 ? WQ : 0) + ((g == 2 % NGRP && tap < XPW) ? 1 : 0);
+                if constexpr (npiece > 0) __builtin_amdgcn_sched_group_barrier(0x010, npiece, 0);
+            });
+        });
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- epilogue: accumulators -> LDS (fp32, swizzled granules) -> compact coalesced loop over consecutive output pixels ----
+    constexpr int G = BN / 4, RPI = NT / G;
+    static_assert(NT % G == 0, "one thread per granule");
+    float *Ct = reinterpret_cast<float *>(smem_n16p);   // the launcher sizes the LDS for 256 * BN floats at least
+    const int g = tid % G, r0 = tid / G;
+    const int c = c0 + g * 4;
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+    static_for<TP>([&](auto B) {
+        constexpr int b = decltype(B)::v;
+        const int ml = (b * WP + wp) * 16 + l15;
+        static_for<TC>([&](auto A) {
+            constexpr int a = decltype(A)::v;
+            const int gg = (wc * TC + a) * 4 + kg;
+            *reinterpret_cast<n_f32x4 *>(Ct + ml * BN + ((gg ^ (ml & 15)) << 2)) = acc[a][b];
+        });
+    });
+    __syncthreads();
+    int ho = 0, wo = 0;
+    if (p.bias9) {
+        const int mm = m0 + r0 < p.M ? m0 + r0 : 0;
+        const int r = mm % (p.Ho * p.Wo);
+        ho = r / p.Wo;
+        wo = r - ho * p.Wo;
+    }
+    for (int ml = r0; ml < BM; ml += RPI) {
+        const int m = m0 + ml;
+        if (m >= p.M) break;
+        const n_f32x4 q = *reinterpret_cast<const n_f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2));
+        float v[4] = {q[0], q[1], q[2], q[3]};
+        if (c < p.Cout) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                s1[t] += v[t];
+                s2[t] += v[t] * v[t];
+            }
+            const float *brow_ = p.bias;
+            if (p.bias9) {
+                const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
+                brow_ = p.bias9 + (size_t)(3 * ry + rx) * p.Cout;
+            }
+            epilogue_store4(p, m, c, v, brow_);
+        }
+        if (p.bias9) {
+            wo += RPI;
+            while (wo >= p.Wo) {
+                wo -= p.Wo;
+                if (++ho == p.Ho) ho = 0;
+            }
+        }
+    }
+    if (p.stats) {
+        __syncthreads();
+        float *red = reinterpret_cast<float *>(smem_n16p);  // [RPI][2][BN]
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            red[(r0 * 2 + 0) * BN + g * 4 + t] = s1[t];
+            red[(r0 * 2 + 1) * BN + g * 4 + t] = s2[t];
+        }
+        __syncthreads();
+        if (tid < BN && c0 + tid < p.Cout) {
+            float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < RPI; ++w) {
+                t1 += red[(w * 2 + 0) * BN + tid];
+                t2 += red[(w * 2 + 1) * BN + tid];
+            }
+            p.stats[((size_t)tile_m * 2 + 0) * p.Cout + c0 + tid] = t1;
+            p.stats[((size_t)tile_m * 2 + 1) * p.Cout + c0 + tid] = t2;
+        }
+    }
+}
+
+// 8-row window pieces per buffer for this conv, or 0 when two buffers do not fit beside the 128-cout weight ring
+static int n16_win_pieces(const ConvArgs &a) {
+    const int np = (256 + 2 * a.W + 2 + 1 + 7) / 8;   // + 1: the last row stays zero (masked taps read it)
+    return np <= 54 ? np : 0;
+}
+
+template <int BN, int WP, int WC>
+static int launch_win(const ConvArgs &a, hipStream_t st) {
+    const int np = n16_win_pieces(a);
+    size_t lds = (size_t)2 * np * 1024 + 3 * (size_t)BN * 128 + 1024;
+    if (lds < (size_t)256 * BN * 4) lds = (size_t)256 * BN * 4;   // the epilogue's accumulator tile
+    const dim3 grid(a.tiles_m * a.tiles_n, 1, 1), block(WP * WC * 64);
+    if (a.narrow == CER_STORE_F16) {
+        auto k = conv_n16_win_kernel<BN, WP, WC, true>;
+        if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CER_LAUNCH(k, grid, block, lds, st, a, np);
+    } else {
+        auto k = conv_n16_win_kernel<BN, WP, WC, false>;
+        if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CER_LAUNCH(k, grid, block, lds, st, a, np);
+    }
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+bool conv_n16_win_ok(const ConvArgs &a) {
+    if (a.KH != 3 || a.KW != 3 || a.stride != 1 || a.dil_h != 1 || a.dil_w != 1 || a.pad_t != 1 || a.pad_l != 1 || a.Ho != a.H ||
+        a.Wo != a.W || a.H < 2 || a.W < 2 || (a.Cin & 63) || a.split_k != 1 || n16_win_pieces(a) == 0)
+        return false;
+    return (long long)(512 + 2 * a.W) * a.x_ld * 2 < (1ll << 31) && (long long)128 * a.Kpad * 2 < (1ll << 31);
+}
+
 template <int BN, int WP, int WC, int XBUFS>
 static int launch_patch(const ConvArgs &a, hipStream_t st) {
     constexpr int XPIECES = 41;
@@ -278,6 +554,12 @@ bool conv_n16_patch_ok(const ConvArgs &a, int tile) {
 }
 
 int conv_n16_patch_launch(int tile, const ConvArgs &a, hipStream_t st) {
+    if (tile == 73 || tile == 74) {
+        if (!conv_n16_win_ok(a))
+            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow, window kernel): needs a 3x3 / stride 1 / pad 1 conv with W <= 86, "
+                                                       "Cin % 64 == 0, no split-K");
+        return tile == 73 ? launch_win<64, 4, 2>(a, st) : launch_win<128, 4, 2>(a, st);
+    }
     if (!conv_n16_patch_ok(a, tile))
         return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow, patch kernel): needs a 3x3 / stride 1 / pad 1 conv on images whose "
                                                    "height and width are multiples of 16, Cin % 64 == 0 (tile 71: Cin == 64), no split-K");

@@ -60,6 +60,12 @@ def test_to_n16_is_round_to_nearest_even_and_from_n16_is_exact():
     (2, 64, 64, 32, 3, 1, 71), (1, 64, 128, 48, 3, 1, 71), (2, 64, 40, 16, 3, 1, 71), (3, 64, 64, 16, 3, 1, 71),
     (2, 128, 128, 32, 3, 1, 72), (1, 128, 256, 32, 3, 1, 72), (1, 256, 128, 16, 3, 1, 72), (3, 64, 100, 32, 3, 1, 72),
     (1, 192, 128, 48, 3, 1, 72),
+    # 1-D window kernels (any image size; 256 consecutive pixels span image rows and images): the 40x40 pyramid (40 / 20 / 10
+    # / 5), the 224x224 pyramid's 56 / 28 / 14 / 7, tiny images (many per tile), ragged M and Cout, the widest image (86)
+    (3, 64, 64, 40, 3, 1, 73), (2, 64, 128, 20, 3, 1, 73), (5, 128, 40, 10, 3, 1, 73), (7, 64, 64, 5, 3, 1, 73),
+    (1, 64, 64, 56, 3, 1, 73), (50, 64, 64, 2, 3, 1, 73), (3, 64, 64, 3, 3, 1, 73),
+    (2, 128, 128, 56, 3, 1, 74), (3, 256, 256, 28, 3, 1, 74), (5, 128, 200, 14, 3, 1, 74), (9, 512, 512, 7, 3, 1, 74),
+    (2, 64, 128, 40, 3, 1, 74), (1, 64, 128, 86, 3, 1, 74), (1, 64, 128, 17, 3, 1, 74),
     # DMA-placement A/B variants of the flat kernels
     (4, 128, 256, 10, 3, 1, 81), (4, 128, 128, 10, 3, 1, 82), (3, 64, 64, 12, 3, 1, 83), (2, 128, 256, 10, 3, 1, 84),
     (4, 128, 256, 10, 3, 1, 91), (7, 256, 512, 5, 3, 2, 91), (2, 128, 256, 10, 3, 1, 94)])
@@ -82,13 +88,15 @@ def test_conv_n16_matches_float64_on_the_same_operands(n, cin, cout, hw, k, stri
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("cin,cout,tile", [(64, 64, 71), (64, 128, 71), (128, 128, 72), (64, 200, 72), (64, 64, 0), (128, 128, 0)])
+@pytest.mark.parametrize("cin,cout,tile", [(64, 64, 71), (64, 128, 71), (128, 128, 72), (64, 200, 72), (64, 64, 0), (128, 128, 0),
+                                           (64, 64, 73), (64, 128, 74), (128, 200, 74)])
 def test_conv_n16_patch_kernel_epilogue_on_non_square_images(cin, cout, tile, dtype):
     """Patch kernels: H != W, bias9 (folded input BatchNorm) + PReLU + narrow residual + statistics; and the automatic
     choice on a shape the picker routes to them."""
     from feature_vs_text_compound_emotion_amd import ops
     g = torch.Generator().manual_seed(cin + cout)
-    n, h, w = (176, 32, 48) if tile == 0 else (2, 32, 48)   # tile 0: enough patches for the picker to choose a patch kernel
+    # tile 0: enough patches for the picker to choose a patch kernel; window kernels: odd sizes, several images per tile
+    n, h, w = (176, 32, 48) if tile == 0 else ((3, 13, 21) if tile in (73, 74) else (2, 32, 48))
     x = torch.randn(n, cin, h, w, generator=g).to(dtype)
     wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(dtype)
     s1, t1 = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.5
@@ -125,6 +133,11 @@ def test_conv_n16_patch_kernel_rejects_what_it_cannot_take():
         ops.conv2d_n16(x, w, 3, 3, pad=(1, 1), tile=71)          # tile 71 keeps ONE window: Cin == 64 only
     with pytest.raises(RuntimeError, match="patch"):
         ops.conv2d_n16(x, w, 3, 3, stride=2, pad=(1, 1), tile=72)
+    with pytest.raises(RuntimeError, match="window"):
+        ops.conv2d_n16(x, w, 3, 3, stride=2, pad=(1, 1), tile=74)
+    x = torch.zeros(1, 4, 100, 128, dtype=torch.bfloat16).cuda()
+    with pytest.raises(RuntimeError, match="window"):
+        ops.conv2d_n16(x, w, 3, 3, pad=(1, 1), tile=73)          # W = 100: two windows do not fit in the LDS
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
