@@ -207,6 +207,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_b3_dma16_kernel
         const int g = tid % G, r0 = tid / G;
         const int c = c0 + g * 4;
         float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+        EpiCtx ec;
+        epi_init(p, c, ec);
         // row / column of the thread's first pixel once (bias9), then stepped without divisions
         int ho = 0, wo = 0;
         if (p.bias9) {
@@ -236,12 +238,8 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_b3_dma16_kernel
                             if (c + e < p.Cout) dst[e] = v[e];
                     }
                 } else {
-                    const float *brow = p.bias;
-                    if (p.bias9) {
-                        const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
-                        brow = p.bias9 + (size_t)(3 * ry + rx) * p.Cout;
-                    }
-                    epilogue_store4(p, m, c, v, brow);
+                    const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
+                    epi_store4(p, ec, m, c, v, 3 * ry + rx);
                 }
             }
             if (p.bias9) {  // advance RPI pixels
@@ -396,13 +394,13 @@ int conv_b3_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
     if (tile == 0) {
         // measured per layer shape on MI355X (tools/bench_conv.py)
         const long long t128 = (M + 127) / 128 * ((Cout + 127) / 128), t256 = (M + 255) / 256;
-        if (b3_patch_geometry(d) && Cout <= 64 && t256 >= 512) tile = 51;
-        else if (b3_patch_geometry(d) && Cout >= 128 && t256 * ((Cout + 127) / 128) >= 512) tile = 52;
+        if (b3_patch_geometry(d) && Cout <= 64 && t256 >= 512) tile = 57;
+        else if (b3_patch_geometry(d) && Cout >= 128 && t256 * ((Cout + 127) / 128) >= 512) tile = 58;
         else if (b3_win_geometry(d) && d->Cin >= 128 && Cout >= 128 && t256 >= 64) {
             // one block per CU (the window fills the LDS): whole rounds of 256 blocks; a 128-cout block does twice the work of
             // a 64-cout block in 1.84x the time (56x56 / 28x28 / 10x10 / 5x5 layers: +17 .. +35 % over the flat 128x128 tile)
             const long long b54 = t256 * ((Cout + 127) / 128), b53 = t256 * ((Cout + 63) / 64);
-            tile = ((b54 + 255) / 256) * 184 <= ((b53 + 255) / 256) * 100 ? 54 : 53;
+            tile = ((b54 + 255) / 256) * 184 <= ((b53 + 255) / 256) * 100 ? 56 : 55;   // ping-pong variants of 54 / 53
         }
         else if (Cout <= 64) tile = t256 >= 512 ? 48 : 42;  // 256x64: 226 vs 204 TF/s on 64->64 @224x224
         else if (t128 >= 512) tile = 41;
@@ -415,10 +413,10 @@ int conv_b3_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         case 44: bm = 64; bn = 128; break;
         case 45: bm = 64; bn = 64; break;
         case 48: bm = 256; bn = 64; break;
-        case 51: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels
-        case 52: bm = 256; bn = 128; break;
-        case 53: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels
-        case 54: bm = 256; bn = 128; break;
+        case 51: case 57: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels (57 / 58: ping-pong phases)
+        case 52: case 58: bm = 256; bn = 128; break;
+        case 53: case 55: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels
+        case 54: case 56: bm = 256; bn = 128; break;   // (55 / 56: ping-pong phases)
         default: return 0;
     }
     return tile;
@@ -431,7 +429,7 @@ int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 44: return launch_b3_dma16<64, 128, 1, 4>(a, st);
         case 45: return launch_b3_dma16<64, 64, 2, 2>(a, st);
         case 48: return launch_b3_dma16<256, 64, 4, 1>(a, st);
-        case 51: case 52: case 53: case 54: return conv_b3_patch_launch(tile, a, st);
+        case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58: return conv_b3_patch_launch(tile, a, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3): unknown tile id");
     }
 }

@@ -23,7 +23,9 @@ namespace cer {
 constexpr unsigned long long B3_PATCH_F_TABLE = 0xaaa00a00ull;
 __device__ __forceinline__ int b3_patch_f(int wx) { return (int)((B3_PATCH_F_TABLE >> (2 * wx)) & 3ull); }
 
-template <int BN, int WP, int WC>
+// PP = ping-pong phases (see conv_b3_win_kernel below): the two waves of a SIMD run half a step apart, one reads while the
+// other streams MFMAs.
+template <int BN, int WP, int WC, bool PP>
 __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs p) {
     constexpr int NW = WP * WC, NT = NW * 64;
     constexpr int PH = 16, PWD = 16, WW = 18, WROWS = 18 * 18;
@@ -36,6 +38,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
     constexpr int WQ = WPIECES / NW;                              // weight pieces per wave and step
     constexpr int TP = PH / WP, TC = BN / (16 * WC);
     static_assert(PH % WP == 0 && XPW <= 9 && TP >= 2, "geometry");
+    static_assert(!PP || (WP == 4 && WC == 2 && (BN / 16) % 4 == 0), "ping-pong: waves w and w + 4 share a SIMD and split the couts");
     constexpr int WOFF = 2 * XBYTES, SINK = WOFF + 3 * WSLICE;    // LDS map: two windows | weight ring | 1 KiB sink
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_b3p[];
@@ -76,10 +79,13 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
     int w_plane[WQ], w_dst[WQ];
 #pragma unroll
     for (int i = 0; i < WQ; ++i) {
-        const int j = wave + NW * i;                 // piece of the slice: plane j / (BN / 16), 16 rows from (j % (BN / 16)) * 16
-        w_plane[i] = j / (BN / 16);
-        const int row = (j % (BN / 16)) * 16 + prow;
-        w_dst[i] = w_plane[i] * WPL + (j % (BN / 16)) * 1024;
+        // PP: the group's own cout half, BN / 32 pieces per plane dealt to its four waves; else all pieces over all waves
+        const int j = PP ? (wave & 3) + 4 * i : wave + NW * i;
+        constexpr int PPL = PP ? BN / 32 : BN / 16;                 // pieces per plane in this wave's pool
+        w_plane[i] = j / PPL;
+        const int pc = (PP ? (wave >> 2) * PPL : 0) + j % PPL;     // piece (16 cout rows) within the plane
+        const int row = pc * 16 + prow;
+        w_dst[i] = w_plane[i] * WPL + pc * 1024;
         w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ swz16((row >> 2) & 3)) << 3)) * 2) : OOB;
     }
     const size_t img = (size_t)n * p.H * p.W * p.x_ld * 2;
@@ -130,6 +136,11 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
     for (int i = 0; i < XPW; ++i) issue_x(i, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
+    if constexpr (PP) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WQ) : "memory");   // the window and slice 0 (slice 1 may still be in flight)
+        __builtin_amdgcn_s_barrier();
+        if (wc == 1) __builtin_amdgcn_s_barrier();                  // group 1 runs one phase behind group 0
+    }
 
     // One step = one filter tap of one 32-channel chunk; per wave and step WQ weight pieces (slice of step s + 2) and, during
     // taps 0 .. XPW-1, the two planes of one window piece of the next chunk.  At the top of step s everything issued before
@@ -138,14 +149,6 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
         const int xcur = (cc & 1) * XBYTES;
         static_for<9>([&](auto T) {
             constexpr int tap = decltype(T)::v, kh = tap / 3, kw = tap % 3;
-            constexpr int ptap = (tap + 8) % 9;
-            constexpr int pcnt = WQ + (ptap < XPW ? 2 : 0);
-            if (cc == 0 && tap == 0) {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");  // prologue: all but slice 1
-            } else {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
-            }
-            __builtin_amdgcn_s_barrier();
             constexpr int ntap = (tap + 2) % 9, nring = (tap + 2) % 3;
             const int ncc = cc + (tap + 2 >= 9 ? 1 : 0);
             const unsigned char *Wr = smem + (tap % 3) * WSLICE;
@@ -154,6 +157,51 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
             // drop the kernel stub)
             auto lda = [&](int a, int pl) { return *reinterpret_cast<const u32x4 *>(Wr + pl * WPL + arow + a * 16 * 64); };
             auto ldb = [&](int b, int pl) { return *reinterpret_cast<const u32x4 *>(Xb + pl * XPL + bcol[kw] + b * WP * WW * 64); };
+            if constexpr (PP) {
+                // ---- READ phase: every fragment of the step, then the step's DMA (slice of step + 2, a window piece) ----
+                u32x4 ah[TC], al[TC], bh[TP], bl[TP];
+#pragma unroll
+                for (int a = 0; a < TC; ++a) { ah[a] = lda(a, 0); al[a] = lda(a, 1); }
+#pragma unroll
+                for (int b = 0; b < TP; ++b) { bh[b] = ldb(b, 0); bl[b] = ldb(b, 1); }
+                issue_w(ncc, ntap, nring);
+                if constexpr (tap < XPW) issue_x(tap, cc + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- MFMA phase: consecutive MFMAs go to different accumulators (lo*hi, hi*lo, hi*hi per accumulator) ----
+#pragma unroll
+                for (int a = 0; a < TC; ++a)
+#pragma unroll
+                    for (int g = 0; g < TP; ++g)
+                        acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < TC; ++a)
+#pragma unroll
+                    for (int g = 0; g < TP; ++g)
+                        acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bl[g]), acc[a][g], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < TC; ++a)
+#pragma unroll
+                    for (int g = 0; g < TP; ++g)
+                        acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
+                // everything this wave issued before this step's READ phase has landed (slice of step + 1, older window pieces)
+                constexpr int cnt = WQ + (tap < XPW ? 2 : 0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cnt) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+            constexpr int ptap = (tap + 8) % 9;
+            constexpr int pcnt = WQ + (ptap < XPW ? 2 : 0);
+            if (cc == 0 && tap == 0) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");  // prologue: all but slice 1
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();
             u32x4 ah[TC], al[TC], bh[TP], bl[TP];
 #pragma unroll
             for (int a = 0; a < TC; ++a) { ah[a] = lda(a, 0); al[a] = lda(a, 1); }
@@ -180,7 +228,11 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
                 constexpr int npiece = (g == 0 ? WQ : 0) + ((g == 1 && tap < XPW) ? 2 : 0);
                 if constexpr (npiece > 0) __builtin_amdgcn_sched_group_barrier(0x010, npiece, 0);
             });
+            }
         });
+    }
+    if constexpr (PP) {
+        if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sink pieces of the last steps
 
@@ -191,6 +243,8 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
     const int g = tid % G, r0 = tid / G, ox = r0 & 15;
     const int c = c0 + g * 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    EpiCtx ec;
+    epi_init(p, c, ec);
     __syncthreads();
     static_for<TP>([&](auto B) {
         constexpr int b = decltype(B)::v;
@@ -216,13 +270,9 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
                 s1[t] += v[t];
                 s2[t] += v[t] * v[t];
             }
-            const float *brow_ = p.bias;
-            if (p.bias9) {
-                const int gy = py * PH + oy;
-                const int ry = gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1);
-                brow_ = p.bias9 + (size_t)(3 * ry + rx) * p.Cout;
-            }
-            epilogue_store4(p, m, c, v, brow_);
+            const int gy = py * PH + oy;
+            const int ry = gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1);
+            epi_store4(p, ec, m, c, v, 3 * ry + rx);
         }
     }
     if (p.stats) {
@@ -259,7 +309,13 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
 // such a lane reads the window's last row, which the DMA zero-fills.  Fragment rows start at any alignment; the swizzle
 // slot = chunk ^ ((row & 4) >> 1) is conflict free for every alignment (tools/check_swizzle.py).  Everything else -- weight
 // ring, counted vmcnt, unrolled taps, read pipeline, DMA placement -- is the patch kernel's.
-template <int BN, int WP, int WC>
+//
+// PP (ping-pong): the two waves that share a SIMD (wave w and w + 4: the cout halves wc = 0 / 1) run half a step out of phase.
+// A step is split into a READ phase (all 16 fragment reads of the step + the step's DMA issue) and an MFMA phase (48 MFMAs,
+// nothing else), with a block barrier after each; group 1 starts one phase late, so while one wave of a SIMD streams MFMAs the
+// other fetches -- the matrix pipe never waits for an LDS read.  Each group DMAs the weight rows of ITS cout half (nobody else
+// reads them), which keeps the two-step latency budget of the ring in both groups.
+template <int BN, int WP, int WC, bool PP>
 __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p, int NP) {
     constexpr int NW = WP * WC, NT = NW * 64, BM = 256;
     constexpr int NPMAX = 27;                                     // window pieces (16 rows) per plane the LDS can hold twice
@@ -269,6 +325,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
     constexpr int WQ = WPIECES / NW;
     constexpr int TP = BM / (16 * WP), TC = BN / (16 * WC);
     static_assert(XPW <= 9 && TP >= 2, "geometry");
+    static_assert(!PP || (WP == 4 && WC == 2 && (BN / 16) % 4 == 0), "ping-pong: waves w and w + 4 share a SIMD and split the couts");
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_b3p[];
     unsigned char *smem = reinterpret_cast<unsigned char *>(smem_b3p);
@@ -309,10 +366,13 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
     int w_plane[WQ], w_dst[WQ];
 #pragma unroll
     for (int i = 0; i < WQ; ++i) {
-        const int j = wave + NW * i;
-        w_plane[i] = j / (BN / 16);
-        const int row = (j % (BN / 16)) * 16 + prow;
-        w_dst[i] = w_plane[i] * WPL + (j % (BN / 16)) * 1024;
+        // PP: the group's own cout half, BN / 32 pieces per plane dealt to its four waves; else all pieces over all waves
+        const int j = PP ? (wave & 3) + 4 * i : wave + NW * i;
+        constexpr int PPL = PP ? BN / 32 : BN / 16;                 // pieces per plane in this wave's pool
+        w_plane[i] = j / PPL;
+        const int pc = (PP ? (wave >> 2) * PPL : 0) + j % PPL;     // piece (16 cout rows) within the plane
+        const int row = pc * 16 + prow;
+        w_dst[i] = w_plane[i] * WPL + pc * 1024;
         w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ swz16((row >> 2) & 3)) << 3)) * 2) : OOB;
     }
     // 64-bit base of the window's first pixel (never dereferenced where it points outside the tensor: those lanes are OOB)
@@ -375,19 +435,16 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
     for (int i = 0; i < XPW; ++i) issue_x(i, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
+    if constexpr (PP) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WQ) : "memory");   // the window and slice 0 (slice 1 may still be in flight)
+        __builtin_amdgcn_s_barrier();
+        if (wc == 1) __builtin_amdgcn_s_barrier();                  // group 1 runs one phase behind group 0
+    }
 
     for (int cc = 0; cc < cin_steps; ++cc) {
         const int xcur = (cc & 1) * XBYTES;
         static_for<9>([&](auto T) {
             constexpr int tap = decltype(T)::v, kh = tap / 3, kw = tap % 3;
-            constexpr int ptap = (tap + 8) % 9;
-            constexpr int pcnt = WQ + (ptap < XPW ? 2 : 0);
-            if (cc == 0 && tap == 0) {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
-            }
-            __builtin_amdgcn_s_barrier();
             constexpr int ntap = (tap + 2) % 9, nring = (tap + 2) % 3;
             const int ncc = cc + (tap + 2 >= 9 ? 1 : 0);
             const unsigned char *Wr = smem + WOFF + (tap % 3) * WSLICE;
@@ -401,6 +458,51 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
                 baddr[b] = row * 64 + ((kg ^ ((row & 4) >> 1)) << 4);
             }
             auto ldb = [&](int b, int pl) { return *reinterpret_cast<const u32x4 *>(Xb + pl * XPL + baddr[b]); };
+            if constexpr (PP) {
+                // ---- READ phase: every fragment of the step, then the step's DMA (slice of step + 2, a window piece) ----
+                u32x4 ah[TC], al[TC], bh[TP], bl[TP];
+#pragma unroll
+                for (int a = 0; a < TC; ++a) { ah[a] = lda(a, 0); al[a] = lda(a, 1); }
+#pragma unroll
+                for (int b = 0; b < TP; ++b) { bh[b] = ldb(b, 0); bl[b] = ldb(b, 1); }
+                issue_w(ncc, ntap, nring);
+                if constexpr (tap < XPW) issue_x(tap, cc + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- MFMA phase: consecutive MFMAs go to different accumulators (lo*hi, hi*lo, hi*hi per accumulator) ----
+#pragma unroll
+                for (int a = 0; a < TC; ++a)
+#pragma unroll
+                    for (int g = 0; g < TP; ++g)
+                        acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < TC; ++a)
+#pragma unroll
+                    for (int g = 0; g < TP; ++g)
+                        acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bl[g]), acc[a][g], 0, 0, 0);
+#pragma unroll
+                for (int a = 0; a < TC; ++a)
+#pragma unroll
+                    for (int g = 0; g < TP; ++g)
+                        acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
+                // everything this wave issued before this step's READ phase has landed (slice of step + 1, older window pieces)
+                constexpr int cnt = WQ + (tap < XPW ? 2 : 0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cnt) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
+            constexpr int ptap = (tap + 8) % 9;
+            constexpr int pcnt = WQ + (ptap < XPW ? 2 : 0);
+            if (cc == 0 && tap == 0) {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
+            }
+            __builtin_amdgcn_s_barrier();
             u32x4 ah[TC], al[TC], bh[TP], bl[TP];
 #pragma unroll
             for (int a = 0; a < TC; ++a) { ah[a] = lda(a, 0); al[a] = lda(a, 1); }
@@ -426,7 +528,11 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
                 constexpr int npiece = (g == 0 ? WQ : 0) + ((g == 1 && tap < XPW) ? 2 : 0);
                 if constexpr (npiece > 0) __builtin_amdgcn_sched_group_barrier(0x010, npiece, 0);
             });
+            }
         });
+    }
+    if constexpr (PP) {
+        if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -437,6 +543,8 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
     const int g = tid % G, r0 = tid / G;
     const int c = c0 + g * 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    EpiCtx ec;
+    epi_init(p, c, ec);
     __syncthreads();
     static_for<TP>([&](auto B) {
         constexpr int b = decltype(B)::v;
@@ -466,12 +574,8 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
                 s1[t] += v[t];
                 s2[t] += v[t] * v[t];
             }
-            const float *brow_ = p.bias;
-            if (p.bias9) {
-                const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
-                brow_ = p.bias9 + (size_t)(3 * ry + rx) * p.Cout;
-            }
-            epilogue_store4(p, m, c, v, brow_);
+            const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
+            epi_store4(p, ec, m, c, v, 3 * ry + rx);
         }
         if (p.bias9) {
             wo += RPI;
@@ -509,22 +613,22 @@ static int b3_win_pieces(const ConvArgs &a) {
     return np <= 27 ? np : 0;                           // 4 * 27 KiB + the 48 KiB weight ring + sink <= 160 KiB: W <= 86
 }
 
-template <int BN, int WP, int WC>
+template <int BN, int WP, int WC, bool PP>
 static int launch_b3_win(const ConvArgs &a, hipStream_t st) {
     const int np = b3_win_pieces(a);
     size_t lds = (size_t)4 * np * 1024 + 3 * (size_t)2 * BN * 64 + 1024;
     if (lds < (size_t)256 * BN * 4) lds = (size_t)256 * BN * 4;   // the epilogue's accumulator tile
-    auto k = conv_b3_win_kernel<BN, WP, WC>;
+    auto k = conv_b3_win_kernel<BN, WP, WC, PP>;
     if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, 1), dim3(WP * WC * 64), lds, st, a, np);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }
 
-template <int BN, int WP, int WC>
+template <int BN, int WP, int WC, bool PP>
 static int launch_b3_patch(const ConvArgs &a, hipStream_t st) {
     const size_t lds = (size_t)2 * 2 * 21 * 1024 + 3 * (size_t)2 * BN * 64 + 1024;
-    auto k = conv_b3_patch_kernel<BN, WP, WC>;
+    auto k = conv_b3_patch_kernel<BN, WP, WC, PP>;
     if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, 1), dim3(WP * WC * 64), lds, st, a);
     CER_HIP_CHECK(hipGetLastError());
@@ -546,18 +650,25 @@ bool conv_b3_win_ok(const ConvArgs &a) {
 }
 
 int conv_b3_patch_launch(int tile, const ConvArgs &a, hipStream_t st) {
-    if (tile == 53 || tile == 54) {
+    if (tile >= 53 && tile <= 56) {
         if (!conv_b3_win_ok(a))
             return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3, window kernel): needs a 3x3 / stride 1 / pad 1 conv with W <= 86, "
                                                        "Cin % 32 == 0, no split-K");
-        return tile == 53 ? launch_b3_win<64, 4, 2>(a, st) : launch_b3_win<128, 4, 2>(a, st);
+        switch (tile) {
+            case 53: return launch_b3_win<64, 4, 2, false>(a, st);
+            case 54: return launch_b3_win<128, 4, 2, false>(a, st);
+            case 55: return launch_b3_win<64, 4, 2, true>(a, st);     // ping-pong variants
+            default: return launch_b3_win<128, 4, 2, true>(a, st);
+        }
     }
     if (!conv_b3_patch_ok(a))
         return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3, patch kernel): needs a 3x3 / stride 1 / pad 1 conv on images whose "
                                                    "height and width are multiples of 16, Cin % 32 == 0, no split-K");
     switch (tile) {
-        case 51: return launch_b3_patch<64, 4, 2>(a, st);
-        case 52: return launch_b3_patch<128, 4, 2>(a, st);
+        case 51: return launch_b3_patch<64, 4, 2, false>(a, st);
+        case 52: return launch_b3_patch<128, 4, 2, false>(a, st);
+        case 57: return launch_b3_patch<64, 4, 2, true>(a, st);      // ping-pong variants
+        case 58: return launch_b3_patch<128, 4, 2, true>(a, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3, patch kernel): unknown tile id");
     }
 }

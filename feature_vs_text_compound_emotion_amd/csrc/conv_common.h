@@ -190,5 +190,101 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c,
     }
 }
 
+// ---- streamlined epilogue for the staged (LDS -> compact row loop) epilogues ----
+// epilogue_store4 above is fully general and costs ~2600 instructions of branch skeleton per call (two activation switches with
+// an erf expansion per element, every optional tensor tested per element); called once per 4 couts it made the store phase of
+// a 256 x 128 tile take 12 us -- more than the tile's MFMA time on the K-short layers.  The encoder's launches use a small
+// subset: bias / border bias (bias9), PReLU or ReLU or no activation, an optional residual, fp32 / split / narrow outputs.
+// EpiCtx decides ONCE per launch (uniformly) whether that subset applies, keeps the thread's per-channel constants in
+// registers (no loads in the row loop besides the residual: a load's vmcnt wait would also wait for the previous rows'
+// stores), and epi_store4 is then ~40 instructions; anything else falls back to epilogue_store4.
+struct EpiCtx {
+    bool fast;
+    float aa[4];      // PReLU slopes of the thread's 4 couts
+    float b9[9][4];   // bias rows of the thread's 4 couts: [0] = p.bias (or zeros), all nine when p.bias9
+};
+
+__device__ __forceinline__ void epi_init(const ConvArgs &p, int c, EpiCtx &e) {
+    e.fast = (p.Cout & 3) == 0 && (p.y_ld & 3) == 0 && p.act2 == CER_ACT_NONE &&
+             (p.act1 == CER_ACT_NONE || p.act1 == CER_ACT_PRELU || p.act1 == CER_ACT_RELU) && !p.mask && !p.aux && !p.y2_hi;
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int t = 0; t < 4; ++t) e.b9[k][t] = 0.f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) e.aa[t] = 0.f;
+    if (!e.fast || c >= p.Cout) return;
+    if (p.bias9) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) {
+            const float4 b = *reinterpret_cast<const float4 *>(p.bias9 + (size_t)k * p.Cout + c);
+            e.b9[k][0] = b.x; e.b9[k][1] = b.y; e.b9[k][2] = b.z; e.b9[k][3] = b.w;
+        }
+    } else if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4 *>(p.bias + c);
+        e.b9[0][0] = b.x; e.b9[0][1] = b.y; e.b9[0][2] = b.z; e.b9[0][3] = b.w;
+    }
+    if (p.act1 == CER_ACT_PRELU) {
+        const float4 a = *reinterpret_cast<const float4 *>(p.alpha + c);
+        e.aa[0] = a.x; e.aa[1] = a.y; e.aa[2] = a.z; e.aa[3] = a.w;
+    }
+}
+
+// cs: the pixel's bias9 case (3 * ry + rx), ignored without bias9
+__device__ __forceinline__ void epi_store4(const ConvArgs &p, const EpiCtx &e, int m, int c, float v[4], int cs) {
+    if (!e.fast) {
+        epilogue_store4(p, m, c, v, p.bias9 ? p.bias9 + (size_t)cs * p.Cout : p.bias);
+        return;
+    }
+    float o[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+        float b = e.b9[0][t];
+        if (p.bias9) {
+#pragma unroll
+            for (int k = 1; k < 9; ++k) b = cs == k ? e.b9[k][t] : b;
+        }
+        o[t] = v[t] + b;
+    }
+    if (p.act1 == CER_ACT_PRELU) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = o[t] >= 0.f ? o[t] : o[t] * e.aa[t];
+    } else if (p.act1 == CER_ACT_RELU) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = o[t] > 0.f ? o[t] : 0.f;
+    }
+    if (p.res || p.res_hi) {
+        size_t roff;
+        if (p.res_stride == 1 && p.Hr == p.Ho && p.Wr == p.Wo) {
+            roff = (size_t)m * p.Cout + c;
+        } else {
+            const int hw = p.Ho * p.Wo;
+            const int n = m / hw, r = m - n * hw;
+            const int ho = r / p.Wo, wo = r - ho * p.Wo;
+            roff = ((size_t)(n * p.Hr + ho * p.res_stride) * p.Wr + wo * p.res_stride) * p.Cout + c;
+        }
+        float rr[4];
+        if (p.res) {
+            const float4 r = *reinterpret_cast<const float4 *>(p.res + roff);
+            rr[0] = r.x; rr[1] = r.y; rr[2] = r.z; rr[3] = r.w;
+        } else if (p.narrow) {
+            load_narrow4(p.res_hi + roff, rr, p.narrow);
+        } else {
+            const ushort4 h = *reinterpret_cast<const ushort4 *>(p.res_hi + roff);
+            const ushort4 l = *reinterpret_cast<const ushort4 *>(p.res_lo + roff);
+            rr[0] = bf16_to_f32(h.x) + bf16_to_f32(l.x); rr[1] = bf16_to_f32(h.y) + bf16_to_f32(l.y);
+            rr[2] = bf16_to_f32(h.z) + bf16_to_f32(l.z); rr[3] = bf16_to_f32(h.w) + bf16_to_f32(l.w);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] += rr[t];
+    }
+    const size_t yoff = (size_t)m * p.y_ld + c;
+    if (p.y) *reinterpret_cast<float4 *>(p.y + yoff) = make_float4(o[0], o[1], o[2], o[3]);
+    if (p.y_hi) {
+        if (p.narrow) store_narrow4(p.y_hi + yoff, o, p.narrow);
+        else store_split4(p.y_hi + yoff, p.y_lo + yoff, o);
+    }
+}
+
 
 }  // namespace cer

@@ -237,6 +237,8 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_kernel(ConvArgs p) {
     const int g = tid % G, r0 = tid / G;
     const int c = c0 + g * 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    EpiCtx ec;
+    epi_init(p, c, ec);
     static_for<NPASS>([&](auto E) {
         constexpr int e = decltype(E)::v;
         __syncthreads();  // the fragment reads of the last step / the previous pass's loop are done
@@ -278,12 +280,8 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_kernel(ConvArgs p) {
                             if (c + t < p.Cout) dst[t] = v[t];
                     }
                 } else {
-                    const float *brow_ = p.bias;
-                    if (p.bias9) {
-                        const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
-                        brow_ = p.bias9 + (size_t)(3 * ry + rx) * p.Cout;
-                    }
-                    epilogue_store4(p, m, c, v, brow_);
+                    const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
+                    epi_store4(p, ec, m, c, v, 3 * ry + rx);
                 }
             }
             if (p.bias9) {  // advance RPI pixels

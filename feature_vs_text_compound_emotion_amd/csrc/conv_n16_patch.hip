@@ -192,6 +192,8 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
     const int g = tid % G, r0 = tid / G, ox = r0 & 15;   // this thread's cout granule, first pixel and patch column
     const int c = c0 + g * 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    EpiCtx ec;
+    epi_init(p, c, ec);
     __syncthreads();  // the fragment reads of the last step are done
     static_for<TP>([&](auto B) {
         constexpr int b = decltype(B)::v;
@@ -217,13 +219,9 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
                 s1[t] += v[t];
                 s2[t] += v[t] * v[t];
             }
-            const float *brow_ = p.bias;
-            if (p.bias9) {
-                const int gy = py * PH + oy;
-                const int ry = gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1);
-                brow_ = p.bias9 + (size_t)(3 * ry + rx) * p.Cout;
-            }
-            epilogue_store4(p, m, c, v, brow_);
+            const int gy = py * PH + oy;
+            const int ry = gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1);
+            epi_store4(p, ec, m, c, v, 3 * ry + rx);
         }
     }
     if (p.stats) {
@@ -426,6 +424,8 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
     const int g = tid % G, r0 = tid / G;
     const int c = c0 + g * 4;
     float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    EpiCtx ec;
+    epi_init(p, c, ec);
     __syncthreads();
     static_for<TP>([&](auto B) {
         constexpr int b = decltype(B)::v;
@@ -455,12 +455,8 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
                 s1[t] += v[t];
                 s2[t] += v[t] * v[t];
             }
-            const float *brow_ = p.bias;
-            if (p.bias9) {
-                const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
-                brow_ = p.bias9 + (size_t)(3 * ry + rx) * p.Cout;
-            }
-            epilogue_store4(p, m, c, v, brow_);
+            const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
+            epi_store4(p, ec, m, c, v, 3 * ry + rx);
         }
         if (p.bias9) {
             wo += RPI;

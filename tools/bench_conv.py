@@ -32,9 +32,15 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--b3", action="store_true", help="bf16x3 kernel (split hi/lo operands)")
     ap.add_argument("--n16", choices=["bf16", "fp16"], default=None, help="narrow kernel (one 16-bit plane per operand)")
+    ap.add_argument("--custom", default="", help="cin,cout,h,k,stride[;...]: these layers (h as given) instead of the IR-50 list")
     a = ap.parse_args()
     scale = a.hw / 40
-    for name, cin, cout, h, k, stride in SHAPES:
+    shapes = SHAPES
+    if a.custom:
+        scale = 1.0
+        shapes = [("%s->%s k%s s%s" % tuple(t.split(",")[i] for i in (0, 1, 3, 4)),) + tuple(int(v) for v in t.split(","))
+                  for t in a.custom.split(";")]
+    for name, cin, cout, h, k, stride in shapes:
         if a.only and a.only not in name:
             continue
         h = int(h * scale)
