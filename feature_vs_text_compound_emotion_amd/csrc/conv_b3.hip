@@ -217,39 +217,41 @@ __global__ __launch_bounds__(NW * 64, NW == 4 ? 2 : 1) void conv_b3_dma16_kernel
             ho = r / p.Wo;
             wo = r - ho * p.Wo;
         }
-        for (int ml = r0; ml < BM; ml += RPI) {
-            const int m = m0 + ml;
-            if (m >= p.M) break;
-            const f32x4 q = *reinterpret_cast<const f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2));
-            float v[4] = {q[0], q[1], q[2], q[3]};
-            if (c < p.Cout) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    s1[e] += v[e];
-                    s2[e] += v[e] * v[e];
-                }
-                if (p.split_k > 1) {
-                    float *dst = p.y + ((size_t)split * p.M + m) * p.Cout + c;
-                    if (((p.Cout & 3) == 0) && c + 3 < p.Cout) {
-                        *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-                            if (c + e < p.Cout) dst[e] = v[e];
+        epi_dispatch(ec.mode, [&](auto MODE_) {
+            for (int ml = r0; ml < BM; ml += RPI) {
+                const int m = m0 + ml;
+                if (m >= p.M) break;
+                const f32x4 q = *reinterpret_cast<const f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2));
+                float v[4] = {q[0], q[1], q[2], q[3]};
+                if (c < p.Cout) {
+    #pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        s1[e] += v[e];
+                        s2[e] += v[e] * v[e];
                     }
-                } else {
-                    const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
-                    epi_store4(p, ec, m, c, v, 3 * ry + rx);
+                    if (p.split_k > 1) {
+                        float *dst = p.y + ((size_t)split * p.M + m) * p.Cout + c;
+                        if (((p.Cout & 3) == 0) && c + 3 < p.Cout) {
+                            *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+    #pragma unroll
+                            for (int e = 0; e < 4; ++e)
+                                if (c + e < p.Cout) dst[e] = v[e];
+                        }
+                    } else {
+                        const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
+                        epi_row<decltype(MODE_)::v>(p, ec, m, c, v, 3 * ry + rx);
+                    }
+                }
+                if (p.bias9) {  // advance RPI pixels
+                    wo += RPI;
+                    while (wo >= p.Wo) {
+                        wo -= p.Wo;
+                        if (++ho == p.Ho) ho = 0;
+                    }
                 }
             }
-            if (p.bias9) {  // advance RPI pixels
-                wo += RPI;
-                while (wo >= p.Wo) {
-                    wo -= p.Wo;
-                    if (++ho == p.Ho) ho = 0;
-                }
-            }
-        }
+        });
         if (p.stats) {
             __syncthreads();  // Ct has been consumed
             float *red = reinterpret_cast<float *>(smem_b3);  // [RPI][2][BN]

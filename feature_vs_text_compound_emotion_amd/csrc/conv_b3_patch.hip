@@ -259,22 +259,24 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
     const int gx = px * PWD + ox;
     const int rx = gx == 0 ? 0 : (gx == p.W - 1 ? 2 : 1);
     const size_t pix0 = ((size_t)n * p.H + (size_t)py * PH) * p.W + gx;
-    for (int oy = r0 >> 4; oy < PH; oy += RPI / 16) {
-        const int ml = oy * 16 + ox;
-        const int m = (int)(pix0 + (size_t)oy * p.W);
-        const f32x4 q = *reinterpret_cast<const f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2));
-        float v[4] = {q[0], q[1], q[2], q[3]};
-        if (c < p.Cout) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                s1[t] += v[t];
-                s2[t] += v[t] * v[t];
+    epi_dispatch(ec.mode, [&](auto MODE_) {
+        for (int oy = r0 >> 4; oy < PH; oy += RPI / 16) {
+            const int ml = oy * 16 + ox;
+            const int m = (int)(pix0 + (size_t)oy * p.W);
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2));
+            float v[4] = {q[0], q[1], q[2], q[3]};
+            if (c < p.Cout) {
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    s1[t] += v[t];
+                    s2[t] += v[t] * v[t];
+                }
+                const int gy = py * PH + oy;
+                const int ry = gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1);
+                epi_row<decltype(MODE_)::v>(p, ec, m, c, v, 3 * ry + rx);
             }
-            const int gy = py * PH + oy;
-            const int ry = gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1);
-            epi_store4(p, ec, m, c, v, 3 * ry + rx);
         }
-    }
+    });
     if (p.stats) {
         __syncthreads();
         float *red = reinterpret_cast<float *>(smem_b3p);  // [RPI][2][BN]
@@ -563,28 +565,30 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
         ho = r / p.Wo;
         wo = r - ho * p.Wo;
     }
-    for (int ml = r0; ml < BM; ml += RPI) {
-        const int m = m0 + ml;
-        if (m >= p.M) break;
-        const f32x4 q = *reinterpret_cast<const f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2));
-        float v[4] = {q[0], q[1], q[2], q[3]};
-        if (c < p.Cout) {
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                s1[t] += v[t];
-                s2[t] += v[t] * v[t];
+    epi_dispatch(ec.mode, [&](auto MODE_) {
+        for (int ml = r0; ml < BM; ml += RPI) {
+            const int m = m0 + ml;
+            if (m >= p.M) break;
+            const f32x4 q = *reinterpret_cast<const f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2));
+            float v[4] = {q[0], q[1], q[2], q[3]};
+            if (c < p.Cout) {
+    #pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    s1[t] += v[t];
+                    s2[t] += v[t] * v[t];
+                }
+                const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
+                epi_row<decltype(MODE_)::v>(p, ec, m, c, v, 3 * ry + rx);
             }
-            const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
-            epi_store4(p, ec, m, c, v, 3 * ry + rx);
-        }
-        if (p.bias9) {
-            wo += RPI;
-            while (wo >= p.Wo) {
-                wo -= p.Wo;
-                if (++ho == p.Ho) ho = 0;
+            if (p.bias9) {
+                wo += RPI;
+                while (wo >= p.Wo) {
+                    wo -= p.Wo;
+                    if (++ho == p.Ho) ho = 0;
+                }
             }
         }
-    }
+    });
     if (p.stats) {
         __syncthreads();
         float *red = reinterpret_cast<float *>(smem_b3p);  // [RPI][2][BN]

@@ -198,8 +198,11 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c,
 // EpiCtx decides ONCE per launch (uniformly) whether that subset applies, keeps the thread's per-channel constants in
 // registers (no loads in the row loop besides the residual: a load's vmcnt wait would also wait for the previous rows'
 // stores), and epi_store4 is then ~40 instructions; anything else falls back to epilogue_store4.
+__device__ __forceinline__ int epi_mode(const ConvArgs &p);
+
 struct EpiCtx {
     bool fast;
+    int mode;         // epi_mode(): EPI_GENERIC or one of the specialised row epilogues
     float aa[4];      // PReLU slopes of the thread's 4 couts
     float b9[9][4];   // bias rows of the thread's 4 couts: [0] = p.bias (or zeros), all nine when p.bias9
 };
@@ -213,6 +216,7 @@ __device__ __forceinline__ void epi_init(const ConvArgs &p, int c, EpiCtx &e) {
         for (int t = 0; t < 4; ++t) e.b9[k][t] = 0.f;
 #pragma unroll
     for (int t = 0; t < 4; ++t) e.aa[t] = 0.f;
+    e.mode = epi_mode(p);
     if (!e.fast || c >= p.Cout) return;
     if (p.bias9) {
 #pragma unroll
@@ -286,5 +290,85 @@ __device__ __forceinline__ void epi_store4(const ConvArgs &p, const EpiCtx &e, i
     }
 }
 
+
+// ---- fully specialised row epilogues for the encoder's launches ----
+// Even the streamlined epi_store4 spends ~20 uniform branches per 4 couts.  The launches that carry the encoder's time use six
+// exact combinations; epi_mode names them once per launch and epi_row<MODE> is straight-line code (~25 instructions):
+//   RAW_F32 / RAW_N16         raw conv result -> fp32 / narrow        (batch-statistics conv2 and shortcut convs, + stats)
+//   B9_PRELU_SPLIT / _N16     + border bias, PReLU -> split / narrow  (conv1 of every unit: its input BatchNorm is folded)
+//   BIAS_RES_SPLIT / _N16     + bias + same-geometry residual         (conv2 of a unit with running statistics)
+// Everything else is EPI_GENERIC = epi_store4.  The interior bias row (case 4) is the common one: the other eight are selected
+// only in waves that hold a border pixel.
+enum { EPI_GENERIC = 0, EPI_RAW_F32, EPI_RAW_N16, EPI_B9_PRELU_SPLIT, EPI_B9_PRELU_N16, EPI_BIAS_RES_SPLIT, EPI_BIAS_RES_N16 };
+
+__device__ __forceinline__ int epi_mode(const ConvArgs &p) {
+    if ((p.Cout & 3) || p.y_ld != p.Cout || p.act2 != CER_ACT_NONE || p.mask || p.aux || p.y2_hi || p.res) return EPI_GENERIC;
+    const bool same_res = p.res_hi && p.res_stride == 1 && p.Hr == p.Ho && p.Wr == p.Wo;
+    if (!p.bias && !p.bias9 && p.act1 == CER_ACT_NONE && !p.res_hi) {
+        if (p.y && !p.y_hi) return EPI_RAW_F32;
+        if (!p.y && p.y_hi && p.narrow) return EPI_RAW_N16;
+    }
+    if (p.bias9 && p.act1 == CER_ACT_PRELU && !p.res_hi && !p.y && p.y_hi) return p.narrow ? EPI_B9_PRELU_N16 : EPI_B9_PRELU_SPLIT;
+    if (p.bias && !p.bias9 && p.act1 == CER_ACT_NONE && same_res && !p.y && p.y_hi) return p.narrow ? EPI_BIAS_RES_N16 : EPI_BIAS_RES_SPLIT;
+    return EPI_GENERIC;
+}
+
+template <class F> __device__ __forceinline__ void epi_dispatch(int mode, F &&f) {
+    switch (mode) {
+        case EPI_RAW_F32: f(IdxC<EPI_RAW_F32>{}); break;
+        case EPI_RAW_N16: f(IdxC<EPI_RAW_N16>{}); break;
+        case EPI_B9_PRELU_SPLIT: f(IdxC<EPI_B9_PRELU_SPLIT>{}); break;
+        case EPI_B9_PRELU_N16: f(IdxC<EPI_B9_PRELU_N16>{}); break;
+        case EPI_BIAS_RES_SPLIT: f(IdxC<EPI_BIAS_RES_SPLIT>{}); break;
+        case EPI_BIAS_RES_N16: f(IdxC<EPI_BIAS_RES_N16>{}); break;
+        default: f(IdxC<EPI_GENERIC>{}); break;
+    }
+}
+
+template <int MODE>
+__device__ __forceinline__ void epi_row(const ConvArgs &p, const EpiCtx &e, int m, int c, float v[4], int cs) {
+    if constexpr (MODE == EPI_GENERIC) {
+        epi_store4(p, e, m, c, v, cs);
+    } else {
+        const size_t off = (size_t)m * p.Cout + c;
+        float o[4] = {v[0], v[1], v[2], v[3]};
+        if constexpr (MODE == EPI_B9_PRELU_SPLIT || MODE == EPI_B9_PRELU_N16) {
+            float b[4] = {e.b9[4][0], e.b9[4][1], e.b9[4][2], e.b9[4][3]};
+            if (cs != 4) {
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    b[t] = e.b9[0][t];
+#pragma unroll
+                    for (int k = 1; k < 9; ++k) b[t] = cs == k ? e.b9[k][t] : b[t];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                o[t] += b[t];
+                o[t] = o[t] >= 0.f ? o[t] : o[t] * e.aa[t];
+            }
+        }
+        if constexpr (MODE == EPI_BIAS_RES_SPLIT || MODE == EPI_BIAS_RES_N16) {
+            float rr[4];
+            if constexpr (MODE == EPI_BIAS_RES_N16) {
+                load_narrow4(p.res_hi + off, rr, p.narrow);
+            } else {
+                const ushort4 h = *reinterpret_cast<const ushort4 *>(p.res_hi + off);
+                const ushort4 l = *reinterpret_cast<const ushort4 *>(p.res_lo + off);
+                rr[0] = bf16_to_f32(h.x) + bf16_to_f32(l.x); rr[1] = bf16_to_f32(h.y) + bf16_to_f32(l.y);
+                rr[2] = bf16_to_f32(h.z) + bf16_to_f32(l.z); rr[3] = bf16_to_f32(h.w) + bf16_to_f32(l.w);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) o[t] = (o[t] + e.b9[0][t]) + rr[t];
+        }
+        if constexpr (MODE == EPI_RAW_F32) {
+            *reinterpret_cast<float4 *>(p.y + off) = make_float4(o[0], o[1], o[2], o[3]);
+        } else if constexpr (MODE == EPI_RAW_N16 || MODE == EPI_B9_PRELU_N16 || MODE == EPI_BIAS_RES_N16) {
+            store_narrow4(p.y_hi + off, o, p.narrow);
+        } else {
+            store_split4(p.y_hi + off, p.y_lo + off, o);
+        }
+    }
+}
 
 }  // namespace cer

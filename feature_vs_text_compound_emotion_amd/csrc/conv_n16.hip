@@ -259,39 +259,41 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_kernel(ConvArgs p) {
             ho = r / p.Wo;
             wo = r - ho * p.Wo;
         }
-        for (int ml = r0; ml < EPR; ml += RPI) {
-            const int m = m0 + e * EPR + ml;
-            if (m >= p.M) break;
-            const n_f32x4 q = *reinterpret_cast<const n_f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2));
-            float v[4] = {q[0], q[1], q[2], q[3]};
-            if (c < p.Cout) {
-#pragma unroll
-                for (int t = 0; t < 4; ++t) {
-                    s1[t] += v[t];
-                    s2[t] += v[t] * v[t];
-                }
-                if (p.split_k > 1) {
-                    float *dst = p.y + ((size_t)split * p.M + m) * p.Cout + c;
-                    if (((p.Cout & 3) == 0) && c + 3 < p.Cout) {
-                        *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t)
-                            if (c + t < p.Cout) dst[t] = v[t];
+        epi_dispatch(ec.mode, [&](auto MODE_) {
+            for (int ml = r0; ml < EPR; ml += RPI) {
+                const int m = m0 + e * EPR + ml;
+                if (m >= p.M) break;
+                const n_f32x4 q = *reinterpret_cast<const n_f32x4 *>(Ct + ml * BN + ((g ^ (ml & 15)) << 2));
+                float v[4] = {q[0], q[1], q[2], q[3]};
+                if (c < p.Cout) {
+    #pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        s1[t] += v[t];
+                        s2[t] += v[t] * v[t];
                     }
-                } else {
-                    const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
-                    epi_store4(p, ec, m, c, v, 3 * ry + rx);
+                    if (p.split_k > 1) {
+                        float *dst = p.y + ((size_t)split * p.M + m) * p.Cout + c;
+                        if (((p.Cout & 3) == 0) && c + 3 < p.Cout) {
+                            *reinterpret_cast<float4 *>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                        } else {
+    #pragma unroll
+                            for (int t = 0; t < 4; ++t)
+                                if (c + t < p.Cout) dst[t] = v[t];
+                        }
+                    } else {
+                        const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
+                        epi_row<decltype(MODE_)::v>(p, ec, m, c, v, 3 * ry + rx);
+                    }
+                }
+                if (p.bias9) {  // advance RPI pixels
+                    wo += RPI;
+                    while (wo >= p.Wo) {
+                        wo -= p.Wo;
+                        if (++ho == p.Ho) ho = 0;
+                    }
                 }
             }
-            if (p.bias9) {  // advance RPI pixels
-                wo += RPI;
-                while (wo >= p.Wo) {
-                    wo -= p.Wo;
-                    if (++ho == p.Ho) ho = 0;
-                }
-            }
-        }
+        });
     });
     if (p.stats) {
         __syncthreads();  // Ct has been consumed
