@@ -42,8 +42,10 @@ KERNEL_NAMES = {41: "cer::conv_b3_dma16_kernel<128, 128, 2, 2, 4, 2>", 42: "cer:
                 53: "cer::conv_b3_win_kernel<64, 4, 2, false>", 54: "cer::conv_b3_win_kernel<128, 4, 2, false>",
                 55: "cer::conv_b3_win_kernel<64, 4, 2, true>", 56: "cer::conv_b3_win_kernel<128, 4, 2, true>",
                 57: "cer::conv_b3_patch_kernel<64, 4, 2, true>", 58: "cer::conv_b3_patch_kernel<128, 4, 2, true>",
-                71: "cer::conv_n16_patch_kernel<64, 4, 1, 1, {f16}>", 72: "cer::conv_n16_patch_kernel<128, 4, 2, 2, {f16}>",
-                73: "cer::conv_n16_win_kernel<64, 4, 2, {f16}>", 74: "cer::conv_n16_win_kernel<128, 4, 2, {f16}>",
+                71: "cer::conv_n16_patch_kernel<64, 4, 1, 1, {f16}, false>", 72: "cer::conv_n16_patch_kernel<128, 4, 2, 2, {f16}, false>",
+                78: "cer::conv_n16_patch_kernel<128, 4, 2, 2, {f16}, true>",
+                73: "cer::conv_n16_win_kernel<64, 4, 2, {f16}, false>", 74: "cer::conv_n16_win_kernel<128, 4, 2, {f16}, false>",
+                75: "cer::conv_n16_win_kernel<64, 4, 2, {f16}, true>", 76: "cer::conv_n16_win_kernel<128, 4, 2, {f16}, true>",
                 91: "cer::conv_n16_kernel<256, 256, 2, 4, {f16}, 2>", 94: "cer::conv_n16_kernel<128, 128, 2, 2, {f16}, 2>",
                 61: "cer::conv_n16_kernel<256, 256, 2, 4, {f16}, 1>", 62: "cer::conv_n16_kernel<256, 128, 4, 2, {f16}, 1>",
                 63: "cer::conv_n16_kernel<256, 64, 4, 1, {f16}, 1>", 64: "cer::conv_n16_kernel<128, 128, 2, 2, {f16}, 1>",

@@ -398,12 +398,8 @@ int conv_b3_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         const long long t128 = (M + 127) / 128 * ((Cout + 127) / 128), t256 = (M + 255) / 256;
         if (b3_patch_geometry(d) && Cout <= 64 && t256 >= 512) tile = 57;
         else if (b3_patch_geometry(d) && Cout >= 128 && t256 * ((Cout + 127) / 128) >= 512) tile = 58;
-        else if (b3_win_geometry(d) && d->Cin >= 128 && Cout >= 128 && t256 >= 64) {
-            // one block per CU (the window fills the LDS): whole rounds of 256 blocks; a 128-cout block does twice the work of
-            // a 64-cout block in 1.84x the time (56x56 / 28x28 / 10x10 / 5x5 layers: +17 .. +35 % over the flat 128x128 tile)
-            const long long b54 = t256 * ((Cout + 127) / 128), b53 = t256 * ((Cout + 63) / 64);
-            tile = ((b54 + 255) / 256) * 184 <= ((b53 + 255) / 256) * 100 ? 56 : 55;   // ping-pong variants of 54 / 53
-        }
+        else if (b3_win_geometry(d) && t256 >= 64) tile = Cout > 64 ? 56 : 55;   // ping-pong window kernels: measured per shape at
+                                                                                 // 40x40, 80x80 and 224x224 input (tools/bench_conv.py)
         else if (Cout <= 64) tile = t256 >= 512 ? 48 : 42;  // 256x64: 226 vs 204 TF/s on 64->64 @224x224
         else if (t128 >= 512) tile = 41;
         else tile = Cout >= 128 ? 44 : 45;

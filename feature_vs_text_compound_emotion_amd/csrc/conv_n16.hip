@@ -381,12 +381,11 @@ int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
     if (tile == 0) {
         const long long t256 = (M + 255) / 256;
         if (patch_geometry(d) && d->Cin == 64 && t256 * ((Cout + 63) / 64) >= 1024) tile = 71;
-        else if (patch_geometry(d) && Cout >= 128 && t256 * ((Cout + 127) / 128) >= 512) tile = 72;
+        else if (patch_geometry(d) && Cout >= 128 && t256 * ((Cout + 127) / 128) >= 512) tile = d->Cin >= 128 ? 78 : 72;  // 78: ping-pong
         else if (win_geometry(d) && t256 >= 64) {
             // one block per CU (the windows fill the LDS): whole rounds of 256 blocks; a 128-cout block does twice the work of
             // a 64-cout block in 1.68x the time (fp16, 1024 frames: 56x56 875 -> 957, 28x28 1066 -> 1158, 5x5 720 -> 939 TF/s)
-            const long long b74 = t256 * ((Cout + 127) / 128), b73 = t256 * ((Cout + 63) / 64);
-            tile = Cout > 64 && ((b74 + 255) / 256) * 168 <= ((b73 + 255) / 256) * 100 ? 74 : 73;
+            tile = Cout > 64 ? 76 : 73;   // 76: ping-pong variant of 74; measured per shape at 40x40 and 224x224 input (tools/bench_conv.py)
         }
         else if (Cout <= 64) tile = t256 >= 512 ? 63 : ((M + 127) / 128 >= 256 ? 65 : 66);
         else if (Cout <= 128) tile = (M + 127) / 128 >= 256 ? 64 : 67;
@@ -404,9 +403,9 @@ int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         case 66: bm = 64; bn = 64; break;
         case 67: bm = 64; bn = 128; break;
         case 71: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels
-        case 72: bm = 256; bn = 128; break;
-        case 73: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels
-        case 74: bm = 256; bn = 128; break;
+        case 72: case 78: bm = 256; bn = 128; break;   // (78: ping-pong phases)
+        case 73: case 75: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels
+        case 74: case 76: bm = 256; bn = 128; break;   // (75 / 76: ping-pong phases)
         default: return 0;
     }
     return tile;
@@ -421,7 +420,7 @@ int conv_n16_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 65: return launch_n16<128, 64, 2, 2>(a, st);
         case 66: return launch_n16<64, 64, 2, 2>(a, st);
         case 67: return launch_n16<64, 128, 1, 4>(a, st);
-        case 71: case 72: case 73: case 74: return conv_n16_patch_launch(tile, a, st);
+        case 71: case 72: case 73: case 74: case 75: case 76: case 78: return conv_n16_patch_launch(tile, a, st);
         case 81: return launch_n16<256, 256, 2, 4, 0>(a, st);
         case 82: return launch_n16<256, 128, 4, 2, 0>(a, st);
         case 83: return launch_n16<256, 64, 4, 1, 0>(a, st);

@@ -28,7 +28,7 @@ namespace cer {
 constexpr unsigned long long PATCH_F_TABLE = 0xd92dad912240ull;
 __device__ __forceinline__ int patch_f(int wx) { return (int)((PATCH_F_TABLE >> (3 * wx)) & 7ull); }
 
-template <int BN, int WP, int WC, int XBUFS, bool F16>
+template <int BN, int WP, int WC, int XBUFS, bool F16, bool PP>
 __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArgs p) {
     constexpr int NW = WP * WC, NT = NW * 64;
     constexpr int PH = 16, PWD = 16, WW = 18, WROWS = 18 * 18;    // patch and window geometry
@@ -40,6 +40,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
     constexpr int WQ = BN / (8 * NW);                               // weight pieces per wave and step
     constexpr int TP = PH / WP, TC = BN / (16 * WC);                // 16x16 MFMA tiles per wave: output rows x cout tiles
     static_assert(PH % WP == 0 && XBUFS >= 1 && XBUFS <= 2 && (XBUFS == 1 || XPW <= 9), "geometry");
+    static_assert(!PP || (WP == 4 && WC == 2 && XBUFS == 2 && (BN / 16) % 4 == 0), "ping-pong: waves w and w + 4 share a SIMD and split the couts");
     constexpr int WOFF = XBUFS * XBYTES, SINK = WOFF + RING * WSLICE;  // LDS map: windows | weight ring | 1 KiB sink
     constexpr unsigned OOB = 0x80000000u;
     constexpr int NGRP = 2 * TP;                                    // MFMA groups (kk, b) per step, TC MFMAs each
@@ -80,9 +81,12 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
         x_off[i] = inb ? (unsigned)(((size_t)iy * p.W + ix) * p.x_ld * 2 + ((slot ^ patch_f(wx)) << 4)) : OOB;
     }
     unsigned w_off[WQ];
+    int w_piece[WQ];
 #pragma unroll
     for (int i = 0; i < WQ; ++i) {
-        const int row = (wave + NW * i) * 8 + prow;
+        // PP: the group's own cout half (BN / 16 pieces of 8 rows) dealt to its four waves; else all pieces over all waves
+        w_piece[i] = PP ? (wave >> 2) * (BN / 16) + (wave & 3) + 4 * i : wave + NW * i;
+        const int row = w_piece[i] * 8 + prow;
         w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ ((row >> 1) & 7)) << 3)) * 2) : OOB;
     }
     const char *ximg = reinterpret_cast<const char *>(p.x_hi) + (size_t)n * p.H * p.W * p.x_ld * 2;
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
             const_cast<char *>(wpanel) + ((size_t)tap * p.Cin + (size_t)cc * 64) * 2, 0, (int)OOB, 0x00020000);
 #pragma unroll
         for (int i = 0; i < WQ; ++i) {
-            unsigned char *dst = real ? smem + WOFF + ring * WSLICE + (wave + NW * i) * 1024 : smem + SINK;
+            unsigned char *dst = real ? smem + WOFF + ring * WSLICE + w_piece[i] * 1024 : smem + SINK;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (n_lds_ptr_t)dst, 16, (int)(real ? w_off[i] : OOB), 0, 0, 0);
         }
     };
@@ -129,6 +133,11 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
     for (int i = 0; i < XPW; ++i) issue_x(i, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
+    if constexpr (PP) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WQ) : "memory");   // the window and slice 0 (slice 1 may still be in flight)
+        __builtin_amdgcn_s_barrier();
+        if (wc == 1) __builtin_amdgcn_s_barrier();                  // group 1 runs one phase behind group 0
+    }
 
     // One step = one filter tap of one 64-channel chunk.  DMA issued per wave and step: WQ weight pieces (slice of step
     // s + 2) and, with two window buffers, one window piece of the next chunk during taps 0 .. XPW-1: CNT(tap) pieces.
@@ -138,22 +147,53 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
         const int xcur = XBUFS == 2 ? (cc & 1) * XBYTES : 0;
         static_for<9>([&](auto T) {
             constexpr int tap = decltype(T)::v, kh = tap / 3, kw = tap % 3;
-            constexpr int ptap = (tap + 8) % 9;                                  // the previous step's tap
-            constexpr int pcnt = WQ + ((XBUFS == 2 && ptap < XPW) ? 1 : 0);      // pieces the previous step issued
-            // (lgkmcnt(0): this wave's fragment reads of the previous step have returned before anyone's DMA may
-            // overwrite the slot / window they came from)
-            if (cc == 0 && tap == 0) {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");  // prologue: all but slice 1
-            } else {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
+            constexpr bool XWIN2 = XBUFS == 2;
+            if constexpr (!PP) {
+                constexpr int ptap = (tap + 8) % 9;                                  // the previous step's tap
+                constexpr int pcnt = WQ + ((XBUFS == 2 && ptap < XPW) ? 1 : 0);      // pieces the previous step issued
+                // (lgkmcnt(0): this wave's fragment reads of the previous step have returned before anyone's DMA may
+                // overwrite the slot / window they came from)
+                if (cc == 0 && tap == 0) {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");  // prologue: all but slice 1
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
+                }
+                __builtin_amdgcn_s_barrier();
             }
-            __builtin_amdgcn_s_barrier();
             constexpr int ntap = (tap + 2) % 9, nring = (tap + 2) % 3;
             const int ncc = cc + (tap + 2 >= 9 ? 1 : 0);
             const unsigned char *Wr = smem + (tap % 3) * WSLICE;
             const unsigned char *Xb = smem + xcur + kh * (WW * 128);
             auto lda = [&](int a, int kk) { return *reinterpret_cast<const n_u32x4 *>(Wr + ((arow + a * 16 * 128) ^ (kk << 6))); };
             auto ldb = [&](int b, int kk) { return *reinterpret_cast<const n_u32x4 *>(Xb + ((bcol[kw] + b * WP * WW * 128) ^ (kk << 6))); };
+            if constexpr (PP) {
+                // ---- READ phase: every fragment of the step, then the step's DMA (slice of step + 2, a window piece) ----
+                n_u32x4 af[2][TC], bf[NGRP];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int a = 0; a < TC; ++a) af[kk][a] = lda(a, kk);
+#pragma unroll
+                for (int g = 0; g < NGRP; ++g) bf[g] = ldb(g % TP, g / TP);
+                issue_w(ncc, ntap, nring);
+                if constexpr (XWIN2 && tap < XPW) issue_x(tap, cc + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- MFMA phase ----
+#pragma unroll
+                for (int g = 0; g < NGRP; ++g)
+#pragma unroll
+                    for (int a = 0; a < TC; ++a) acc[a][g % TP] = mfma_n16<F16>(af[g / TP][a], bf[g], acc[a][g % TP]);
+                // everything this wave issued before this step's READ phase has landed (slice of step + 1, older window pieces)
+                constexpr int cnt = WQ + ((XWIN2 && tap < XPW) ? 1 : 0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cnt) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
             n_u32x4 af[2][TC], bf[NGRP];
 #pragma unroll
             for (int a = 0; a < TC; ++a) af[0][a] = lda(a, 0);
@@ -181,7 +221,11 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
                 constexpr int npiece = (g == 0 ? WQ : 0) + ((g == 2 % NGRP && XBUFS == 2 && tap < XPW) ? 1 : 0);
                 if constexpr (npiece > 0) __builtin_amdgcn_sched_group_barrier(0x010, npiece, 0);
             });
+            }
         });
+    }
+    if constexpr (PP) {
+        if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sink pieces of the last steps
 
@@ -257,7 +301,11 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
 // tap is a row shift kh W + kw of the fragment address.  Taps outside the image (zero padding; in the flat array they are the
 // neighbouring image row / frame) are masked per lane: the lane reads the window's last row, which the DMA zero-fills.
 // Fragment rows start at any alignment: slot = chunk ^ (row & 6) is conflict free for all of them (tools/check_swizzle.py).
-template <int BN, int WP, int WC, bool F16>
+// PP (ping-pong): the two waves that share a SIMD (w and w + 4: the cout halves wc = 0 / 1) run half a step apart: a step is a
+// READ phase (all 16 fragment reads + the step's DMA issue) and an MFMA phase (32 MFMAs, nothing else) with a block barrier
+// after each, and group 1 starts one phase late, so one wave of a SIMD streams MFMAs while the other fetches.  Each group DMAs
+// the weight rows of its own cout half (the other group never reads them): both keep the ring's two-step latency budget.
+template <int BN, int WP, int WC, bool F16, bool PP>
 __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs p, int NP) {
     constexpr int NW = WP * WC, NT = NW * 64, BM = 256;
     constexpr int NPMAX = 54;                                       // 8-row window pieces per buffer the LDS can hold twice (W <= 86)
@@ -267,6 +315,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
     constexpr int WQ = BN / (8 * NW);
     constexpr int TP = BM / (16 * WP), TC = BN / (16 * WC);
     static_assert(XPW <= 9 && TP >= 2, "geometry");
+    static_assert(!PP || (WP == 4 && WC == 2 && (BN / 16) % 4 == 0), "ping-pong: waves w and w + 4 share a SIMD and split the couts");
     constexpr unsigned OOB = 0x80000000u;
     constexpr int NGRP = 2 * TP;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_n16p[];
@@ -304,9 +353,12 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
         x_off[i] = inb ? (unsigned)(((size_t)row * p.x_ld + ((slot ^ (row & 6)) << 3)) * 2) : OOB;
     }
     unsigned w_off[WQ];
+    int w_piece[WQ];
 #pragma unroll
     for (int i = 0; i < WQ; ++i) {
-        const int row = (wave + NW * i) * 8 + prow;
+        // PP: the group's own cout half (BN / 16 pieces of 8 rows) dealt to its four waves; else all pieces over all waves
+        w_piece[i] = PP ? (wave >> 2) * (BN / 16) + (wave & 3) + 4 * i : wave + NW * i;
+        const int row = w_piece[i] * 8 + prow;
         w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ ((row >> 1) & 7)) << 3)) * 2) : OOB;
     }
     // base of the window's first pixel; lanes whose pixel lies outside the tensor carry the out-of-range offset instead
@@ -325,7 +377,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
             const_cast<char *>(wpanel) + ((size_t)tap * p.Cin + (size_t)cc * 64) * 2, 0, (int)OOB, 0x00020000);
 #pragma unroll
         for (int i = 0; i < WQ; ++i) {
-            unsigned char *dst = real ? smem + WOFF + ring * WSLICE + (wave + NW * i) * 1024 : smem + SINK;
+            unsigned char *dst = real ? smem + WOFF + ring * WSLICE + w_piece[i] * 1024 : smem + SINK;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (n_lds_ptr_t)dst, 16, (int)(real ? w_off[i] : OOB), 0, 0, 0);
         }
     };
@@ -363,19 +415,27 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
     for (int i = 0; i < XPW; ++i) issue_x(i, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
+    if constexpr (PP) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WQ) : "memory");   // the window and slice 0 (slice 1 may still be in flight)
+        __builtin_amdgcn_s_barrier();
+        if (wc == 1) __builtin_amdgcn_s_barrier();                  // group 1 runs one phase behind group 0
+    }
 
     for (int cc = 0; cc < cin_steps; ++cc) {
         const int xcur = (cc & 1) * XBYTES;
         static_for<9>([&](auto T) {
             constexpr int tap = decltype(T)::v, kh = tap / 3, kw = tap % 3;
-            constexpr int ptap = (tap + 8) % 9;
-            constexpr int pcnt = WQ + (ptap < XPW ? 1 : 0);
-            if (cc == 0 && tap == 0) {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
+            constexpr bool XWIN2 = true;
+            if constexpr (!PP) {
+                constexpr int ptap = (tap + 8) % 9;
+                constexpr int pcnt = WQ + (ptap < XPW ? 1 : 0);
+                if (cc == 0 && tap == 0) {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
+                }
+                __builtin_amdgcn_s_barrier();
             }
-            __builtin_amdgcn_s_barrier();
             constexpr int ntap = (tap + 2) % 9, nring = (tap + 2) % 3;
             const int ncc = cc + (tap + 2 >= 9 ? 1 : 0);
             const unsigned char *Wr = smem + WOFF + (tap % 3) * WSLICE;
@@ -389,6 +449,34 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
             }
             auto lda = [&](int a, int kk) { return *reinterpret_cast<const n_u32x4 *>(Wr + ((arow + a * 16 * 128) ^ (kk << 6))); };
             auto ldb = [&](int b, int kk) { return *reinterpret_cast<const n_u32x4 *>(Xb + (baddr[b] ^ (kk << 6))); };
+            if constexpr (PP) {
+                // ---- READ phase: every fragment of the step, then the step's DMA (slice of step + 2, a window piece) ----
+                n_u32x4 af[2][TC], bf[NGRP];
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                    for (int a = 0; a < TC; ++a) af[kk][a] = lda(a, kk);
+#pragma unroll
+                for (int g = 0; g < NGRP; ++g) bf[g] = ldb(g % TP, g / TP);
+                issue_w(ncc, ntap, nring);
+                if constexpr (XWIN2 && tap < XPW) issue_x(tap, cc + 1);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- MFMA phase ----
+#pragma unroll
+                for (int g = 0; g < NGRP; ++g)
+#pragma unroll
+                    for (int a = 0; a < TC; ++a) acc[a][g % TP] = mfma_n16<F16>(af[g / TP][a], bf[g], acc[a][g % TP]);
+                // everything this wave issued before this step's READ phase has landed (slice of step + 1, older window pieces)
+                constexpr int cnt = WQ + ((XWIN2 && tap < XPW) ? 1 : 0);
+                __builtin_amdgcn_sched_barrier(0);
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(cnt) : "memory");
+                __builtin_amdgcn_sched_barrier(0);
+                __builtin_amdgcn_s_barrier();
+                __builtin_amdgcn_sched_barrier(0);
+            } else {
             n_u32x4 af[2][TC], bf[NGRP];
 #pragma unroll
             for (int a = 0; a < TC; ++a) af[0][a] = lda(a, 0);
@@ -415,7 +503,11 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
                 constexpr int npiece = (g == 0 ? WQ : 0) + ((g == 2 % NGRP && tap < XPW) ? 1 : 0);
                 if constexpr (npiece > 0) __builtin_amdgcn_sched_group_barrier(0x010, npiece, 0);
             });
+            }
         });
+    }
+    if constexpr (PP) {
+        if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -498,18 +590,18 @@ static int n16_win_pieces(const ConvArgs &a) {
     return np <= 54 ? np : 0;
 }
 
-template <int BN, int WP, int WC>
+template <int BN, int WP, int WC, bool PP>
 static int launch_win(const ConvArgs &a, hipStream_t st) {
     const int np = n16_win_pieces(a);
     size_t lds = (size_t)2 * np * 1024 + 3 * (size_t)BN * 128 + 1024;
     if (lds < (size_t)256 * BN * 4) lds = (size_t)256 * BN * 4;   // the epilogue's accumulator tile
     const dim3 grid(a.tiles_m * a.tiles_n, 1, 1), block(WP * WC * 64);
     if (a.narrow == CER_STORE_F16) {
-        auto k = conv_n16_win_kernel<BN, WP, WC, true>;
+        auto k = conv_n16_win_kernel<BN, WP, WC, true, PP>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CER_LAUNCH(k, grid, block, lds, st, a, np);
     } else {
-        auto k = conv_n16_win_kernel<BN, WP, WC, false>;
+        auto k = conv_n16_win_kernel<BN, WP, WC, false, PP>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CER_LAUNCH(k, grid, block, lds, st, a, np);
     }
@@ -524,17 +616,17 @@ bool conv_n16_win_ok(const ConvArgs &a) {
     return (long long)(512 + 2 * a.W) * a.x_ld * 2 < (1ll << 31) && (long long)128 * a.Kpad * 2 < (1ll << 31);
 }
 
-template <int BN, int WP, int WC, int XBUFS>
+template <int BN, int WP, int WC, int XBUFS, bool PP>
 static int launch_patch(const ConvArgs &a, hipStream_t st) {
     constexpr int XPIECES = 41;
     const size_t lds = (size_t)XBUFS * XPIECES * 1024 + 3 * (size_t)BN * 128 + 1024;
     const dim3 grid(a.tiles_m * a.tiles_n, 1, 1), block(WP * WC * 64);
     if (a.narrow == CER_STORE_F16) {
-        auto k = conv_n16_patch_kernel<BN, WP, WC, XBUFS, true>;
+        auto k = conv_n16_patch_kernel<BN, WP, WC, XBUFS, true, PP>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CER_LAUNCH(k, grid, block, lds, st, a);
     } else {
-        auto k = conv_n16_patch_kernel<BN, WP, WC, XBUFS, false>;
+        auto k = conv_n16_patch_kernel<BN, WP, WC, XBUFS, false, PP>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CER_LAUNCH(k, grid, block, lds, st, a);
     }
@@ -550,22 +642,28 @@ bool conv_n16_patch_ok(const ConvArgs &a, int tile) {
         return false;
     if ((long long)a.H * a.W * a.x_ld * 2 >= (1ll << 31) || (long long)128 * a.Kpad * 2 >= (1ll << 31)) return false;
     if (tile == 71) return a.Cin == 64;
-    return tile == 72;
+    return tile == 72 || tile == 78;
 }
 
 int conv_n16_patch_launch(int tile, const ConvArgs &a, hipStream_t st) {
-    if (tile == 73 || tile == 74) {
+    if (tile >= 73 && tile <= 76) {
         if (!conv_n16_win_ok(a))
             return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow, window kernel): needs a 3x3 / stride 1 / pad 1 conv with W <= 86, "
                                                        "Cin % 64 == 0, no split-K");
-        return tile == 73 ? launch_win<64, 4, 2>(a, st) : launch_win<128, 4, 2>(a, st);
+        switch (tile) {
+            case 73: return launch_win<64, 4, 2, false>(a, st);
+            case 74: return launch_win<128, 4, 2, false>(a, st);
+            case 75: return launch_win<64, 4, 2, true>(a, st);      // ping-pong variants
+            default: return launch_win<128, 4, 2, true>(a, st);
+        }
     }
     if (!conv_n16_patch_ok(a, tile))
         return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow, patch kernel): needs a 3x3 / stride 1 / pad 1 conv on images whose "
                                                    "height and width are multiples of 16, Cin % 64 == 0 (tile 71: Cin == 64), no split-K");
     switch (tile) {
-        case 71: return launch_patch<64, 4, 1, 1>(a, st);
-        case 72: return launch_patch<128, 4, 2, 2>(a, st);
+        case 71: return launch_patch<64, 4, 1, 1, false>(a, st);
+        case 72: return launch_patch<128, 4, 2, 2, false>(a, st);
+        case 78: return launch_patch<128, 4, 2, 2, true>(a, st);     // ping-pong variant of 72
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (narrow, patch kernel): unknown tile id");
     }
 }

@@ -66,6 +66,10 @@ def test_to_n16_is_round_to_nearest_even_and_from_n16_is_exact():
     (1, 64, 64, 56, 3, 1, 73), (50, 64, 64, 2, 3, 1, 73), (3, 64, 64, 3, 3, 1, 73),
     (2, 128, 128, 56, 3, 1, 74), (3, 256, 256, 28, 3, 1, 74), (5, 128, 200, 14, 3, 1, 74), (9, 512, 512, 7, 3, 1, 74),
     (2, 64, 128, 40, 3, 1, 74), (1, 64, 128, 86, 3, 1, 74), (1, 64, 128, 17, 3, 1, 74),
+    # the same with ping-pong phases (the two waves of a SIMD half a step apart)
+    (3, 64, 64, 40, 3, 1, 75), (5, 128, 40, 10, 3, 1, 75), (50, 64, 64, 2, 3, 1, 75), (1, 64, 64, 56, 3, 1, 75),
+    (2, 128, 128, 56, 3, 1, 76), (3, 256, 256, 28, 3, 1, 76), (5, 128, 200, 14, 3, 1, 76), (9, 512, 512, 7, 3, 1, 76),
+    (1, 64, 128, 86, 3, 1, 76), (2, 128, 128, 32, 3, 1, 78), (1, 256, 128, 16, 3, 1, 78), (3, 64, 100, 32, 3, 1, 78),
     # DMA-placement A/B variants of the flat kernels
     (4, 128, 256, 10, 3, 1, 81), (4, 128, 128, 10, 3, 1, 82), (3, 64, 64, 12, 3, 1, 83), (2, 128, 256, 10, 3, 1, 84),
     (4, 128, 256, 10, 3, 1, 91), (7, 256, 512, 5, 3, 2, 91), (2, 128, 256, 10, 3, 1, 94)])
@@ -89,14 +93,14 @@ def test_conv_n16_matches_float64_on_the_same_operands(n, cin, cout, hw, k, stri
 
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("cin,cout,tile", [(64, 64, 71), (64, 128, 71), (128, 128, 72), (64, 200, 72), (64, 64, 0), (128, 128, 0),
-                                           (64, 64, 73), (64, 128, 74), (128, 200, 74)])
+                                           (64, 64, 73), (64, 128, 74), (128, 200, 74), (64, 64, 75), (128, 200, 76), (128, 128, 78)])
 def test_conv_n16_patch_kernel_epilogue_on_non_square_images(cin, cout, tile, dtype):
     """Patch kernels: H != W, bias9 (folded input BatchNorm) + PReLU + narrow residual + statistics; and the automatic
     choice on a shape the picker routes to them."""
     from feature_vs_text_compound_emotion_amd import ops
     g = torch.Generator().manual_seed(cin + cout)
     # tile 0: enough patches for the picker to choose a patch kernel; window kernels: odd sizes, several images per tile
-    n, h, w = (176, 32, 48) if tile == 0 else ((3, 13, 21) if tile in (73, 74) else (2, 32, 48))
+    n, h, w = (176, 32, 48) if tile == 0 else ((3, 13, 21) if tile in (73, 74, 75, 76) else (2, 32, 48))
     x = torch.randn(n, cin, h, w, generator=g).to(dtype)
     wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(dtype)
     s1, t1 = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.5
