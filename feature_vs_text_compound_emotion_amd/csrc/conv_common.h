@@ -325,15 +325,50 @@ template <class F> __device__ __forceinline__ void epi_dispatch(int mode, F &&f)
     }
 }
 
+// the specialised modes on an already chosen bias vector b4 (ignored by the RAW modes) and PReLU slopes aa
+template <int MODE>
+__device__ __forceinline__ void epi_row_core(const ConvArgs &p, const float aa[4], const float b4[4], int m, int c, const float v[4]) {
+    static_assert(MODE != EPI_GENERIC, "specialised modes only");
+    const size_t off = (size_t)m * p.Cout + c;
+    float o[4] = {v[0], v[1], v[2], v[3]};
+    if constexpr (MODE == EPI_B9_PRELU_SPLIT || MODE == EPI_B9_PRELU_N16) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            o[t] += b4[t];
+            o[t] = o[t] >= 0.f ? o[t] : o[t] * aa[t];
+        }
+    }
+    if constexpr (MODE == EPI_BIAS_RES_SPLIT || MODE == EPI_BIAS_RES_N16) {
+        float rr[4];
+        if constexpr (MODE == EPI_BIAS_RES_N16) {
+            load_narrow4(p.res_hi + off, rr, p.narrow);
+        } else {
+            const ushort4 h = *reinterpret_cast<const ushort4 *>(p.res_hi + off);
+            const ushort4 l = *reinterpret_cast<const ushort4 *>(p.res_lo + off);
+            rr[0] = bf16_to_f32(h.x) + bf16_to_f32(l.x); rr[1] = bf16_to_f32(h.y) + bf16_to_f32(l.y);
+            rr[2] = bf16_to_f32(h.z) + bf16_to_f32(l.z); rr[3] = bf16_to_f32(h.w) + bf16_to_f32(l.w);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = (o[t] + b4[t]) + rr[t];
+    }
+    if constexpr (MODE == EPI_RAW_F32) {
+        *reinterpret_cast<float4 *>(p.y + off) = make_float4(o[0], o[1], o[2], o[3]);
+    } else if constexpr (MODE == EPI_RAW_N16 || MODE == EPI_B9_PRELU_N16 || MODE == EPI_BIAS_RES_N16) {
+        store_narrow4(p.y_hi + off, o, p.narrow);
+    } else {
+        store_split4(p.y_hi + off, p.y_lo + off, o);
+    }
+}
+
 template <int MODE>
 __device__ __forceinline__ void epi_row(const ConvArgs &p, const EpiCtx &e, int m, int c, float v[4], int cs) {
     if constexpr (MODE == EPI_GENERIC) {
         epi_store4(p, e, m, c, v, cs);
     } else {
-        const size_t off = (size_t)m * p.Cout + c;
-        float o[4] = {v[0], v[1], v[2], v[3]};
+        float b[4] = {e.b9[0][0], e.b9[0][1], e.b9[0][2], e.b9[0][3]};
         if constexpr (MODE == EPI_B9_PRELU_SPLIT || MODE == EPI_B9_PRELU_N16) {
-            float b[4] = {e.b9[4][0], e.b9[4][1], e.b9[4][2], e.b9[4][3]};
+#pragma unroll
+            for (int t = 0; t < 4; ++t) b[t] = e.b9[4][t];
             if (cs != 4) {
 #pragma unroll
                 for (int t = 0; t < 4; ++t) {
@@ -342,32 +377,8 @@ __device__ __forceinline__ void epi_row(const ConvArgs &p, const EpiCtx &e, int 
                     for (int k = 1; k < 9; ++k) b[t] = cs == k ? e.b9[k][t] : b[t];
                 }
             }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                o[t] += b[t];
-                o[t] = o[t] >= 0.f ? o[t] : o[t] * e.aa[t];
-            }
         }
-        if constexpr (MODE == EPI_BIAS_RES_SPLIT || MODE == EPI_BIAS_RES_N16) {
-            float rr[4];
-            if constexpr (MODE == EPI_BIAS_RES_N16) {
-                load_narrow4(p.res_hi + off, rr, p.narrow);
-            } else {
-                const ushort4 h = *reinterpret_cast<const ushort4 *>(p.res_hi + off);
-                const ushort4 l = *reinterpret_cast<const ushort4 *>(p.res_lo + off);
-                rr[0] = bf16_to_f32(h.x) + bf16_to_f32(l.x); rr[1] = bf16_to_f32(h.y) + bf16_to_f32(l.y);
-                rr[2] = bf16_to_f32(h.z) + bf16_to_f32(l.z); rr[3] = bf16_to_f32(h.w) + bf16_to_f32(l.w);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) o[t] = (o[t] + e.b9[0][t]) + rr[t];
-        }
-        if constexpr (MODE == EPI_RAW_F32) {
-            *reinterpret_cast<float4 *>(p.y + off) = make_float4(o[0], o[1], o[2], o[3]);
-        } else if constexpr (MODE == EPI_RAW_N16 || MODE == EPI_B9_PRELU_N16 || MODE == EPI_BIAS_RES_N16) {
-            store_narrow4(p.y_hi + off, o, p.narrow);
-        } else {
-            store_split4(p.y_hi + off, p.y_lo + off, o);
-        }
+        epi_row_core<MODE>(p, e.aa, b, m, c, v);
     }
 }
 
