@@ -61,14 +61,17 @@ _SIGNATURES = {
     "cer_weight_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
     "cer_conv1d_wgrad": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cer_conv2d_wgrad": (c_int, [_P, _P, _P] + [c_int] * 12 + [_P]),
+    "cer_conv2d_wgrad_b3_workspace_bytes": (c_size_t, [c_int] * 7),
+    "cer_conv2d_wgrad_b3": (c_int, [_P, _P, _P] + [c_int] * 12 + [_P, c_size_t, _P]),
     "cer_prelu_fwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
     "cer_prelu_bwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, _P]),
     "cer_col_sum_workspace_bytes": (c_size_t, [c_int, c_int]),
     "cer_col_sum": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
     "cer_act_mask_bwd": (c_int, [_P, _P, _P, _P, c_size_t, c_float, _P]),
     "cer_tblock_tail_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_size_t, c_float, _P]),
+    "cer_bn_rows_fwd_workspace_bytes": (c_size_t, [c_int, c_int]),
     "cer_bn_rows_fwd": (c_int, [_P, c_int, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float,
-                                c_float, _P]),
+                                c_float, _P, c_size_t, _P]),
     "cer_bn_rows_bwd": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P, c_size_t,
                                 _P]),
     "cer_lfan_attn_fwd": (c_int, [POINTER(_P), _P, _P, c_int, c_int, c_int, c_int, _P]),

@@ -56,7 +56,8 @@ __global__ void weight_norm_bwd_kernel(const float *__restrict__ dw, const float
 }
 
 // ------------------------------------------------------------- column sums
-// out[c] = sum_r a[r][c] * (b ? (b[r][c]-mean[c])*invstd[c] : 1).  Block = 32 columns x 8 row
+// out[c] = sum_r a[r][c] * (b ? (b[r][c]-mean[c])*invstd[c] : 1)  (a == NULL with b: sum_r ((b-mean)*invstd)^2, the
+// centred second moment of the row BatchNorm statistics).  Block = 32 columns x 8 row
 // lanes; grid.x = column chunks, grid.y = row slabs (partials [grid.y][C] reduced by a
 // second launch with b == NULL) -> deterministic.
 __global__ void col_sum_kernel(const float *__restrict__ a, int a_ld, const float *__restrict__ b, int b_ld,
@@ -69,10 +70,17 @@ __global__ void col_sum_kernel(const float *__restrict__ a, int a_ld, const floa
     float s = 0.f;
     if (c < C) {
         const float mu = mean ? mean[c] : 0.f, is = invstd ? invstd[c] : 1.f;
-        for (int r = r0 + ry; r < r1; r += 8) {
-            float v = a[(size_t)r * a_ld + c];
-            if (b) v *= (b[(size_t)r * b_ld + c] - mu) * is;
-            s += v;
+        if (a) {
+            for (int r = r0 + ry; r < r1; r += 8) {
+                float v = a[(size_t)r * a_ld + c];
+                if (b) v *= (b[(size_t)r * b_ld + c] - mu) * is;
+                s += v;
+            }
+        } else {
+            for (int r = r0 + ry; r < r1; r += 8) {
+                const float d = (b[(size_t)r * b_ld + c] - mu) * is;
+                s += d * d;
+            }
         }
     }
     red[ry][cx] = s;
@@ -526,7 +534,7 @@ extern "C" size_t cer_col_sum_workspace_bytes(int R, int C) {
 extern "C" int cer_col_sum(const float *a, int a_ld, const float *b, int b_ld, const float *mean,
                            const float *invstd, float *out, int R, int C, void *workspace, size_t workspace_bytes,
                            void *stream) {
-    if (!a || !out || R <= 0 || C <= 0 || a_ld < C || (b && b_ld < C))
+    if ((!a && !(b && mean)) || !out || R <= 0 || C <= 0 || (a && a_ld < C) || (b && b_ld < C))
         return cer_set_error(CER_ERR_INVALID_ARG, "col_sum: bad argument");
     const int slabs = (R + 255) / 256;
     dim3 grid((C + 31) / 32, slabs);
@@ -565,16 +573,49 @@ extern "C" int cer_tblock_tail_bwd(const float *dout, const float *out, const fl
     return CER_OK;
 }
 
+// large R: the statistics as two deterministic column sums (the block-per-32-channels kernel above walks all R rows
+// serially: 3-7 ms at the released encoder units' R = 25600 .. 102400 rows)
+__global__ void bn_rows_mean_kernel(float *__restrict__ sum_to_mean, int R, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) sum_to_mean[c] /= (float)R;
+}
+__global__ void bn_rows_finish_kernel(const float *__restrict__ mean, float *__restrict__ ssd_to_invstd,
+                                      float *__restrict__ running_mean, float *__restrict__ running_var, int R, int C,
+                                      float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float var = ssd_to_invstd[c] / (float)R;   // sum (x - mean)^2
+    var = var > 0.f ? var : 0.f;
+    ssd_to_invstd[c] = rsqrtf(var + eps);
+    if (running_mean) {
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean[c];
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * var * (float)R / (float)max(R - 1, 1);
+    }
+}
+
+extern "C" size_t cer_bn_rows_fwd_workspace_bytes(int R, int C) { return R > 2048 ? cer_col_sum_workspace_bytes(R, C) : 0; }
+
 extern "C" int cer_bn_rows_fwd(const float *x, int x_ld, const float *w, const float *b, float *running_mean,
                                float *running_var, float *save_mean, float *save_invstd, float *y, int y_ld, int R,
-                               int C, int train, float eps, float momentum, void *stream) {
+                               int C, int train, float eps, float momentum, void *workspace, size_t workspace_bytes,
+                               void *stream) {
     if (!x || !w || !b || !y || R <= 0 || C <= 0 || x_ld < C || y_ld < C || !running_mean || !running_var)
         return cer_set_error(CER_ERR_INVALID_ARG, "bn_rows_fwd: bad argument");
     const size_t n = (size_t)R * C;
     if (train) {
         if (!save_mean || !save_invstd) return cer_set_error(CER_ERR_INVALID_ARG, "bn_rows_fwd: train needs save buffers");
-        CER_LAUNCH(bn_rows_stats_kernel, dim3((C + 31) / 32), dim3(256), 0, ST, x, x_ld, save_mean, save_invstd,
-                           running_mean, running_var, R, C, eps, momentum);
+        if (R > 2048) {
+            int rc = cer_col_sum(x, x_ld, nullptr, 0, nullptr, nullptr, save_mean, R, C, workspace, workspace_bytes, stream);
+            if (rc) return rc;
+            CER_LAUNCH(bn_rows_mean_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, save_mean, R, C);
+            rc = cer_col_sum(nullptr, 0, x, x_ld, save_mean, nullptr, save_invstd, R, C, workspace, workspace_bytes, stream);
+            if (rc) return rc;
+            CER_LAUNCH(bn_rows_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, (const float *)save_mean, save_invstd,
+                       running_mean, running_var, R, C, eps, momentum);
+        } else {
+            CER_LAUNCH(bn_rows_stats_kernel, dim3((C + 31) / 32), dim3(256), 0, ST, x, x_ld, save_mean, save_invstd,
+                               running_mean, running_var, R, C, eps, momentum);
+        }
         CER_LAUNCH(bn_rows_apply_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, ST, x, x_ld,
                            (const float *)save_mean, (const float *)save_invstd, 0, eps, w, b, y, y_ld, R, C);
     } else {

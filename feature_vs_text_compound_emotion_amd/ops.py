@@ -459,13 +459,22 @@ def l2norm_rows(x):
     return y
 
 
-def conv2d_wgrad(dz, x, kh, kw, stride=1, pad=(0, 0)):
-    """dW [Cout,Cin,KH,KW] (torch layout) from dz [N,Ho,Wo,Cout] and the conv input x [N,H,W,Cin] (both dense NHWC)."""
+def conv2d_wgrad(dz, x, kh, kw, stride=1, pad=(0, 0), b3=False):
+    """dW [Cout,Cin,KH,KW] (torch layout) from dz [N,Ho,Wo,Cout] and the conv input x [N,H,W,Cin] (both dense NHWC).
+    ``b3``: the bf16x3 MFMA kernel with the pixel range split over blocks (Cout, Cin % 128 == 0; other shapes take the
+    fp32-MFMA kernel either way)."""
     _dev_f32(dz, "dz")
     _dev_f32(x, "x")
     n, ho, wo, cout = dz.shape
     _, h, w, cin = x.shape
     dw = _empty((cout, cin, kh, kw), dz)
+    if b3 and cout % 128 == 0 and cin % 128 == 0:
+        lib = _lib.load()
+        nbytes = lib.cer_conv2d_wgrad_b3_workspace_bytes(n, ho, wo, cout, cin, kh, kw)
+        ws = _empty((nbytes // 4,), dz) if nbytes else None
+        check(lib.cer_conv2d_wgrad_b3(ptr(dz), ptr(x), ptr(dw), n, h, w, ho, wo, cout, cin, kh, kw, stride, pad[0], pad[1],
+                                      ptr(ws), nbytes, current_stream()), "cer_conv2d_wgrad_b3")
+        return dw
     check(_lib.load().cer_conv2d_wgrad(ptr(dz), ptr(x), ptr(dw), n, h, w, ho, wo, cout, cin, kh, kw, stride, pad[0], pad[1],
                                        current_stream()), "cer_conv2d_wgrad")
     return dw
@@ -711,9 +720,12 @@ def bn_rows_fwd(x, w, b, running_mean, running_var, train, eps=1e-5, momentum=0.
     _, _, y_ld = _rows(out, "out")
     sm = _empty((c,), x) if train else None
     si = _empty((c,), x) if train else None
-    check(_lib.load().cer_bn_rows_fwd(ptr(x), x_ld, ptr(w), ptr(b), ptr(running_mean), ptr(running_var), ptr(sm),
-                                      ptr(si), ptr(out), y_ld, r, c, 1 if train else 0, eps, momentum,
-                                      current_stream()), "cer_bn_rows_fwd")
+    lib = _lib.load()
+    nbytes = lib.cer_bn_rows_fwd_workspace_bytes(r, c) if train else 0
+    ws = _empty((nbytes // 4,), x) if nbytes else None
+    check(lib.cer_bn_rows_fwd(ptr(x), x_ld, ptr(w), ptr(b), ptr(running_mean), ptr(running_var), ptr(sm),
+                              ptr(si), ptr(out), y_ld, r, c, 1 if train else 0, eps, momentum, ptr(ws), nbytes,
+                              current_stream()), "cer_bn_rows_fwd")
     return out, sm, si
 
 

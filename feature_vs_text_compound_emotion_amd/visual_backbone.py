@@ -44,7 +44,22 @@ class _Flatten(nn.Module):
     pass
 
 
-def _conv_dgrad(dy, w_oihw, stride, pad, in_hw):
+def _conv_prec(x, wp, kh, kw, stride, pad, prec):
+    """Dense NHWC fp32 in / out; the arithmetic of the encoder's precision mode: "bf16x3" (split operands, three MFMAs per
+    product, <= 2^-15 relative per product), narrow storage ("bf16" / "fp16": operands rounded once, one MFMA), or the exact
+    fp32 kernels.  Used by the released units' forward and data-gradient convs (the reference runs them in the same
+    arithmetic as the rest of the encoder: fp32, or fp16 under --amp autocast)."""
+    if prec == "bf16x3":
+        return ops.conv2d_b3(ops.split_bf16(x), ops.split_bf16(wp), kh, kw, stride=stride, pad=pad, out_f32=True,
+                             out_split=False)["y"]
+    if prec in ("bf16", "fp16"):
+        dt = torch.bfloat16 if prec == "bf16" else torch.float16
+        return ops.conv2d_n16(ops.to_n16(x, dt), ops.to_n16(wp, dt), kh, kw, stride=stride, pad=pad, out_f32=True,
+                              out_n16=False)["y"]
+    return ops.conv2d(x, wp, kh, kw, stride=stride, pad=pad)
+
+
+def _conv_dgrad(dy, w_oihw, stride, pad, in_hw, prec="fp32"):
     """Data gradient of a conv (fp32 kernels): the forward kernel on the transposed + flipped filter with padding
     k-1-pad; for stride > 1 the output gradient is first spread onto the stride grid of a zero image sized so that this
     is a NATURAL convolution geometry (H_up + 2(k-1-pad) - k + 1 == H_in)."""
@@ -56,7 +71,7 @@ def _conv_dgrad(dy, w_oihw, stride, pad, in_hw):
         up = torch.zeros((n, hu, wu, c), device=dy.device, dtype=dy.dtype)
         up[:, :(ho - 1) * stride + 1:stride, :(wo - 1) * stride + 1:stride] = dy
         dy = up
-    return ops.conv2d(dy, wt, kh, kw, pad=(kh - 1 - pad, kw - 1 - pad))
+    return _conv_prec(dy, wt, kh, kw, 1, (kh - 1 - pad, kw - 1 - pad), prec)
 
 
 class _ReleasedUnit(torch.autograd.Function):
@@ -66,15 +81,15 @@ class _ReleasedUnit(torch.autograd.Function):
     TN weight-gradient GEMM, PReLU fwd/bwd."""
 
     @staticmethod
-    def forward(ctx, x, u, g1, b1, w1, a1, w2, g2, b2, ws, gs, bs):
+    def forward(ctx, x, u, prec, g1, b1, w1, a1, w2, g2, b2, ws, gs, bs):
         n, h, w, cin = x.shape
         bn1, bn2, s = u.res_layer[0], u.res_layer[4], u.stride
         xb, sm1, si1 = ops.bn_rows_fwd(x.view(-1, cin), g1.detach(), b1.detach(), bn1.running_mean, bn1.running_var, True,
                                        bn1.eps, bn1.momentum)
         xb = xb.view(n, h, w, cin)
-        z1 = ops.conv2d(xb, ops.pack_conv_weight(w1.detach().contiguous()), 3, 3, pad=(1, 1))
+        z1 = _conv_prec(xb, ops.pack_conv_weight(w1.detach().contiguous()), 3, 3, 1, (1, 1), prec)
         t1 = ops.prelu_fwd(z1, a1.detach().contiguous())
-        z2 = ops.conv2d(t1, ops.pack_conv_weight(w2.detach().contiguous()), 3, 3, stride=s, pad=(1, 1))
+        z2 = _conv_prec(t1, ops.pack_conv_weight(w2.detach().contiguous()), 3, 3, s, (1, 1), prec)
         _, ho, wo, depth = z2.shape
         out, sm2, si2 = ops.bn_rows_fwd(z2.view(-1, depth), g2.detach(), b2.detach(), bn2.running_mean, bn2.running_var, True,
                                         bn2.eps, bn2.momentum)
@@ -82,7 +97,7 @@ class _ReleasedUnit(torch.autograd.Function):
         zs = sms = sis = None
         if ws is not None:
             bns = u.shortcut_layer[1]
-            zs = ops.conv2d(x, ops.pack_conv_weight(ws.detach().contiguous()), 1, 1, stride=s)
+            zs = _conv_prec(x, ops.pack_conv_weight(ws.detach().contiguous()), 1, 1, s, (0, 0), prec)
             sc, sms, sis = ops.bn_rows_fwd(zs.view(-1, depth), gs.detach(), bs.detach(), bns.running_mean, bns.running_var, True,
                                            bns.eps, bns.momentum)
             ops.add_inplace(out, sc.view(n, ho, wo, depth))
@@ -92,38 +107,40 @@ class _ReleasedUnit(torch.autograd.Function):
                               w2.detach(), g2.detach(), ws.detach() if ws is not None else None,
                               gs.detach() if gs is not None else None)
         ctx.stride = s
+        ctx.prec = prec
         return out
 
     @staticmethod
     def backward(ctx, dout):
         x, xb, z1, t1, z2, sm1, si1, sm2, si2, zs, sms, sis, g1, w1, a1, w2, g2, ws, gs = ctx.saved_tensors
-        s = ctx.stride
+        s, prec = ctx.stride, ctx.prec
         n, h, w, cin = x.shape
         _, ho, wo, depth = z2.shape
         dout = dout.contiguous()
         dz2, dg2, db2 = ops.bn_rows_bwd(dout.view(-1, depth), z2.view(-1, depth), sm2, si2, g2)
         dz2 = dz2.view(n, ho, wo, depth)
-        dw2 = ops.conv2d_wgrad(dz2, t1, 3, 3, stride=s, pad=(1, 1))
-        dt1 = _conv_dgrad(dz2, w2, s, 1, (h, w))
+        b3 = prec != "fp32"   # the weight gradients follow the convs onto the bf16x3 matrix-core kernel
+        dw2 = ops.conv2d_wgrad(dz2, t1, 3, 3, stride=s, pad=(1, 1), b3=b3)
+        dt1 = _conv_dgrad(dz2, w2, s, 1, (h, w), prec)
         dz1, da1 = ops.prelu_bwd(dt1, z1, a1.contiguous())
-        dw1 = ops.conv2d_wgrad(dz1, xb, 3, 3, stride=1, pad=(1, 1))
+        dw1 = ops.conv2d_wgrad(dz1, xb, 3, 3, stride=1, pad=(1, 1), b3=b3)
         need_dx = ctx.needs_input_grad[0]
-        dxb = _conv_dgrad(dz1, w1, 1, 1, (h, w))
+        dxb = _conv_dgrad(dz1, w1, 1, 1, (h, w), prec)
         dx, dg1, db1 = ops.bn_rows_bwd(dxb.view(-1, cin), x.view(-1, cin), sm1, si1, g1)
         dx = dx.view(n, h, w, cin)
         dws = dgs = dbs = None
         if ws is not None:
             dzs, dgs, dbs = ops.bn_rows_bwd(dout.view(-1, depth), zs.view(-1, depth), sms, sis, gs)
             dzs = dzs.view(n, ho, wo, depth)
-            dws = ops.conv2d_wgrad(dzs, x, 1, 1, stride=s, pad=(0, 0))
+            dws = ops.conv2d_wgrad(dzs, x, 1, 1, stride=s, pad=(0, 0), b3=b3)
             if need_dx:
-                ops.add_inplace(dx, _conv_dgrad(dzs, ws, s, 0, (h, w)))
+                ops.add_inplace(dx, _conv_dgrad(dzs, ws, s, 0, (h, w), prec))
         elif need_dx:
             if s > 1:
                 dx[:, ::s, ::s] += dout
             else:
                 ops.add_inplace(dx, dout)
-        return (dx if need_dx else None), None, dg1, db1, dw1, da1, dw2, dg2, db2, dws, dgs, dbs
+        return (dx if need_dx else None), None, None, dg1, db1, dw1, da1, dw2, dg2, db2, dws, dgs, dbs
 
 
 class _ReleasedHead(torch.autograd.Function):
@@ -457,8 +474,8 @@ class IR50(nn.Module):
         first_released = len(P["units"]) if plan is None else plan
         y = None
         for i, (u, d) in enumerate(zip(self.body, P["units"])):
-            if i >= first_released:  # released for training: exact-fp32 path with a backward
-                y = self._released_unit(u, y)
+            if i >= first_released:  # released for training: fp32 tensors, convs in this mode's arithmetic, with a backward
+                y = self._released_unit(u, y, "fp16" if dtype == torch.float16 else "bf16")
                 continue
             last = i + 1 == first_released  # the next consumer (released unit or head) wants fp32
             s1, t1 = self._finalize(xst, ys.numel() // u.cin, u.res_layer[0])
@@ -544,8 +561,8 @@ class IR50(nn.Module):
         first_released = len(P["units"]) if plan is None else plan
         y = None
         for i, (u, d) in enumerate(zip(self.body, P["units"])):
-            if i >= first_released:  # released for training: exact-fp32 path with a backward
-                y = self._released_unit(u, y)
+            if i >= first_released:  # released for training: fp32 tensors, bf16x3 forward / data-gradient convs, with a backward
+                y = self._released_unit(u, y, "bf16x3")
                 continue
             last = i + 1 == first_released  # the next consumer (released unit or head) wants fp32
             s1, t1 = self._finalize(xst, ys.hi.numel() // u.cin, u.res_layer[0])
@@ -621,10 +638,10 @@ class IR50(nn.Module):
         return first
 
     @staticmethod
-    def _released_unit(u, y):
+    def _released_unit(u, y, prec="fp32"):
         pr = u.res_layer
         sc = u.shortcut_layer if u.cin != u.depth else None
-        return _ReleasedUnit.apply(y, u, pr[0].weight, pr[0].bias, pr[1].weight, pr[2].weight, pr[3].weight, pr[4].weight,
+        return _ReleasedUnit.apply(y, u, prec, pr[0].weight, pr[0].bias, pr[1].weight, pr[2].weight, pr[3].weight, pr[4].weight,
                                    pr[4].bias, sc[0].weight if sc is not None else None,
                                    sc[1].weight if sc is not None else None, sc[1].bias if sc is not None else None)
 

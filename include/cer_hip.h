@@ -208,6 +208,14 @@ int cer_conv1d_wgrad(const float *dz, int dz_ld, const float *x, int x_ld, float
  * (zero outside the image).  dz dense [N*Ho*Wo, Cout], x dense NHWC, dw in torch's OIHW layout. */
 int cer_conv2d_wgrad(const float *dz, const float *x, float *dw, int N, int H, int W, int Ho, int Wo, int Cout, int Cin,
                      int KH, int KW, int stride, int pad_t, int pad_l, void *stream);
+/* The same on the bf16 matrix cores with split hi/lo operands ("bf16x3": three MFMAs per product, <= 2^-15 relative per
+ * product, fp32 accumulation), the pixel range split over blocks and reduced in a fixed order: the weight gradient of the
+ * reference's released encoder units (base/parameter_control.py:55-103 un-freezes IR-50 stage 4 and half of stage 3; their
+ * backward is torch autograd's conv2d weight gradient, models/arcface_model.py:44-60).  Cout and Cin must be multiples of 128
+ * (CER_ERR_UNSUPPORTED otherwise: use cer_conv2d_wgrad). */
+size_t cer_conv2d_wgrad_b3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW);
+int cer_conv2d_wgrad_b3(const float *dz, const float *x, float *dw, int N, int H, int W, int Ho, int Wo, int Cout, int Cin,
+                        int KH, int KW, int stride, int pad_t, int pad_l, void *workspace, size_t workspace_bytes, void *stream);
 
 /* Channels-last PReLU with per-channel slopes (arcface_model.py:54).  Backward: dx = x > 0 ? dy : alpha*dy, and
  * dalpha_terms = x > 0 ? 0 : x*dy, whose column sum (cer_col_sum) is the slope gradient. */
@@ -215,7 +223,8 @@ int cer_prelu_fwd(const float *x, const float *alpha, float *y, size_t rows, int
 int cer_prelu_bwd(const float *dy, const float *x, const float *alpha, float *dx, float *dalpha_terms, size_t rows, int C,
                   void *stream);
 
-/* out[c] = sum_r a[r][c] * (b ? (b[r][c]-mean[c])*invstd[c] : 1); deterministic tree.
+/* out[c] = sum_r a[r][c] * (b ? (b[r][c]-mean[c])*invstd[c] : 1); a == NULL (with b and mean): the centred second moment
+ * sum_r ((b[r][c]-mean[c])*invstd[c])^2; deterministic tree.
  * Bias gradients and the BatchNorm / LayerNorm parameter gradients. */
 size_t cer_col_sum_workspace_bytes(int R, int C);
 int cer_col_sum(const float *a, int a_ld, const float *b, int b_ld, const float *mean, const float *invstd,
@@ -231,9 +240,10 @@ int cer_tblock_tail_bwd(const float *dout, const float *out, const float *a2, co
 /* BatchNorm1d over rows (reference models/model.py:475,515).  train != 0: batch statistics,
  * running stats updated in place (unbiased variance, `momentum`), save_mean/save_invstd written.
  * train == 0: running statistics. */
+size_t cer_bn_rows_fwd_workspace_bytes(int R, int C);   /* 0 for R <= 2048; larger R reduce the statistics in two column sums */
 int cer_bn_rows_fwd(const float *x, int x_ld, const float *w, const float *b, float *running_mean,
                     float *running_var, float *save_mean, float *save_invstd, float *y, int y_ld,
-                    int R, int C, int train, float eps, float momentum, void *stream);
+                    int R, int C, int train, float eps, float momentum, void *workspace, size_t workspace_bytes, void *stream);
 int cer_bn_rows_bwd(const float *dy, int dy_ld, const float *x, int x_ld, const float *save_mean,
                     const float *save_invstd, const float *w, float *dx, float *dw, float *db,
                     int R, int C, int train, void *workspace, size_t workspace_bytes, void *stream);

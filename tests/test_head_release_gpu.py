@@ -173,6 +173,42 @@ def test_conv2d_wgrad_and_dgrad_vs_autograd(n, cin, cout, hw, k, stride):
     assert (dx.cpu().permute(0, 3, 1, 2) - x.grad).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("n,cin,cout,hw,k,stride,prec", [
+    (40, 128, 128, 10, 3, 1, "bf16x3"), (300, 256, 128, 5, 3, 1, "bf16x3"), (37, 128, 256, 10, 3, 2, "bf16x3"),
+    (50, 128, 256, 9, 1, 2, "bf16x3"), (3, 128, 128, 7, 3, 1, "bf16x3"), (40, 128, 128, 10, 3, 1, "fp16")])
+def test_conv2d_wgrad_b3_and_dgrad_in_the_encoder_precision(n, cin, cout, hw, k, stride, prec):
+    """The matrix-core weight gradient (transposed LDS reads, split operands, pixel range split over blocks and reduced in a
+    fixed order) and the data gradient on the bf16x3 / narrow conv kernels, against float64 autograd.  Error model: every
+    product drops lo*lo and rounds both lo parts: <= 2^-15 sum |dz| |x| (bf16x3); the narrow data gradient rounds both
+    operands once (2^-11 fp16)."""
+    import torch.nn.functional as F
+    from feature_vs_text_compound_emotion_amd import ops
+    from feature_vs_text_compound_emotion_amd.visual_backbone import _conv_dgrad
+    gen = torch.Generator().manual_seed(n + cin + cout)
+    x = torch.randn(n, cin, hw, hw, generator=gen, dtype=torch.float64, requires_grad=True)
+    w = (torch.randn(cout, cin, k, k, generator=gen, dtype=torch.float64) / (cin * k * k) ** 0.5).requires_grad_(True)
+    y = F.conv2d(x, w, None, stride, k // 2)
+    dy = torch.randn(y.shape, generator=gen, dtype=torch.float64)
+    y.backward(dy)
+    # magnitude sums for the bounds: the same contractions on absolute values
+    xa, wa = x.detach().abs().requires_grad_(True), w.detach().abs().requires_grad_(True)
+    F.conv2d(xa, wa, None, stride, k // 2).backward(dy.abs())
+    dz = dy.float().permute(0, 2, 3, 1).contiguous().cuda()
+    xd = x.detach().float().permute(0, 2, 3, 1).contiguous().cuda()
+    dw = ops.conv2d_wgrad(dz, xd, k, k, stride=stride, pad=(k // 2, k // 2), b3=True)
+    npix = n * y.shape[2] * y.shape[3]
+    bound = wa.grad * (2.0 ** -15 + npix * 2.0 ** -24) + 1e-6
+    err = (dw.cpu().double() - w.grad).abs()
+    assert (err <= bound).all(), (err / bound).max().item()
+    ref_fp32 = ops.conv2d_wgrad(dz, xd, k, k, stride=stride, pad=(k // 2, k // 2))          # the fp32-MFMA kernel agrees
+    assert (ref_fp32.cpu().double() - w.grad).abs().max().item() < 1e-3 * max(1.0, w.grad.abs().max().item())
+    dx = _conv_dgrad(dz, w.detach().float().cuda(), stride, k // 2, (hw, hw), prec)
+    eps = 2.0 ** -15 if prec == "bf16x3" else 2.0 ** -10
+    bound = xa.grad * (eps + cout * k * k * 2.0 ** -24) + 1e-6
+    err = (dx.cpu().double().permute(0, 3, 1, 2) - x.grad).abs()
+    assert (err <= bound).all(), (err / bound).max().item()
+
+
 def test_prelu_fwd_bwd_vs_autograd():
     import torch.nn.functional as F
     from feature_vs_text_compound_emotion_amd import ops

@@ -88,6 +88,28 @@ def test_bn_rows_fwd_bwd_train_and_eval():
         _close(db, b.grad, 1e-4)
 
 
+def test_bn_rows_fwd_large_r_statistics_are_column_sums():
+    """R > 2048 (the released encoder units: 25600 .. 102400 rows): mean / variance through two deterministic column sums
+    instead of the block-per-32-channels walk; same results as torch on data with a large mean (the sum x (x - mean) form
+    does not cancel)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(13)
+    r, c = 30011, 96
+    x = torch.randn(r, c, generator=g, dtype=torch.float64) * (torch.rand(c, generator=g, dtype=torch.float64) + 0.2) + \
+        torch.randn(c, generator=g, dtype=torch.float64) * 8
+    w, b = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g)
+    rm, rv = torch.randn(c, generator=g) * 0.1, torch.rand(c, generator=g) + 0.5
+    rm64, rv64 = rm.double().clone(), rv.double().clone()
+    y = F.batch_norm(x, rm64, rv64, w.double(), b.double(), True, 0.1, 1e-5)
+    rm_d, rv_d = rm.clone().cuda(), rv.clone().cuda()
+    yd, sm, si = ops.bn_rows_fwd(x.float().cuda(), w.cuda(), b.cuda(), rm_d, rv_d, True)
+    assert (yd.cpu().double() - y).abs().max().item() < 2e-4          # fp32 storage of x with |mean| ~ 8: 1e-6 * 8 / std
+    assert (sm.cpu().double() - x.mean(0)).abs().max().item() < 2e-5
+    assert ((si.cpu().double() - 1 / torch.sqrt(x.var(0, unbiased=False) + 1e-5)).abs() * x.std(0)).max().item() < 2e-4
+    assert (rm_d.cpu().double() - rm64).abs().max().item() < 1e-5
+    assert ((rv_d.cpu().double() - rv64).abs() / rv64).max().item() < 1e-4
+
+
 def test_cross_entropy_fwd_bwd():
     from feature_vs_text_compound_emotion_amd.lfan import cross_entropy_loss
     g = torch.Generator().manual_seed(4)
