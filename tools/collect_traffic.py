@@ -19,7 +19,7 @@ def total(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     s, n = 0.0, 0
     for r in csv.DictReader(open(f)):
-        if any(k in r["Kernel_Name"] for k in ("conv_igemm_kernel", "conv_b3", "conv_n16_kernel", "conv_n16_patch")) and \
+        if any(k in r["Kernel_Name"] for k in ("conv_igemm_kernel", "conv_b3", "conv_n16")) and \
                 r["Counter_Name"] == counter:
             s += float(r["Counter_Value"])
             n += 1
