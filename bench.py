@@ -216,9 +216,14 @@ class Workload:
         self.model.train()
         if cfg["release"]:
             from feature_vs_text_compound_emotion_amd.parameter_control import ResnetParamControl
-            pc = ResnetParamControl(trainer=None, release_count=cfg["release"])
-            for _ in range(cfg["release"]):
+            pc = ResnetParamControl(trainer=None, release_count=min(cfg["release"], 3))
+            for _ in range(min(cfg["release"], 3)):
                 pc.release_param(self.model.spatial)
+            if cfg["release"] == 4:   # extension (BASELINE configs[1]): backward through the whole IR-50, stem included
+                bb = self.model.spatial["visual"].backbone
+                for part in (bb.input_layer, bb.body, bb.output_layer):
+                    for p in part.parameters():
+                        p.requires_grad = True
         self.ddp = ClipDataParallel(self.model, world_size=world)
         # the reference's torch.optim.SGD(momentum .9, nesterov, wd 1e-4, lr 1e-3 -- F8) as one fused launch over flat buffers
         self.opt = FlatNesterovSGD(self.ddp, lr=1e-3, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=True)
@@ -443,9 +448,10 @@ def main():
                     help="IR-50 conv kernels: bf16x3 = split hi/lo bf16 operands, 3 bf16 MFMAs per product (logit error ~1e-6); "
                          "fp32 = exact fp32 MFMA; bf16 / fp16 = narrow storage, one MFMA per product, fp32 accumulate (what the "
                          "reference's --amp recipe computes; BASELINE cfg5)")
-    ap.add_argument("--release", type=int, default=0, choices=[0, 1, 2, 3],
+    ap.add_argument("--release", type=int, default=0, choices=[0, 1, 2, 3, 4],
                     help="gradual-release groups of the reference's ResnetParamControl to un-freeze before timing "
-                         "(0 = as the reference trains: encoder frozen; 1 = output layer; 2 = + stage 4; 3 = + half of stage 3)")
+                         "(0 = as the reference trains: encoder frozen; 1 = output layer; 2 = + stage 4; 3 = + half of stage 3; "
+                         "4 = extension: the whole IR-50 trains, forward + backward through every unit and the stem)")
     ap.add_argument("--encoders", choices=["on", "off"], default="on",
                     help="on: VGGish (log-mel from PCM) and BERT (64 tokens) run on the GPU inside the step; "
                          "off: pre-computed per-frame features, as the reference trainer feeds them")

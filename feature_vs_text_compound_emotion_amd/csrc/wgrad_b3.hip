@@ -8,7 +8,8 @@
 // gfx950's transposing LDS read ds_read_b64_tr_b16: per 16-lane group it takes a 4-row x 16-column block of 16-bit elements
 // and hands lane i column i of the four rows -- two of them are one MFMA operand (8 pixels of one channel).
 //
-//   * block = 4 waves, output tile 128 couts x 128 cins of ONE filter tap; wave (wi, wj) owns 64 x 64 = 4 x 4 MFMA tiles;
+//   * block = 4 waves, output tile 128 couts x 128 cins of ONE filter tap (channel counts that are not multiples of 128 use
+//     part of it: columns past Cout / Cin are loaded as zeros); wave (wi, wj) owns 64 x 64 = 4 x 4 MFMA tiles;
 //   * K step = 32 pixels: dZ tile [32][128] and the tap-shifted X tile [32][128] (zero rows where the tap leaves the
 //     image), each as two bf16 planes of 8 KiB, double buffered (64 KiB: two blocks per CU);
 //   * LDS image: plain 256-byte rows, 16-byte chunk ch of row r at 256 r + 16 (ch ^ (((r & 3) << 2) | ((r >> 2) & 3))):
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
     const int kg = lane >> 4, l15 = lane & 15;
-    const int tiles_ci = p.Cin / 128;
+    const int tiles_ci = (p.Cin + 127) / 128;
     const int co0 = (blockIdx.x / tiles_ci) * 128, ci0 = (blockIdx.x % tiles_ci) * 128;
     const int tap = blockIdx.y, kh = tap / p.KW, kw = tap - kh * p.KW;
     const int r_begin = blockIdx.z * p.rows_per_split;
@@ -59,11 +60,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
             const int r = r0 + lrow + 8 * i;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < r_end) {
-                a = *reinterpret_cast<const float4 *>(p.dz + (size_t)r * p.Cout + co0 + col4);
+                // (channel counts are multiples of 4; columns past Cout / Cin stay zero: 64-channel layers and the 3 -> 4
+                // channel stem use part of the 128 x 128 tile)
+                if (co0 + col4 < p.Cout) a = *reinterpret_cast<const float4 *>(p.dz + (size_t)r * p.Cout + co0 + col4);
                 const int n = r / hw, q = r - n * hw;
                 const int ho = q / p.Wo, wo = q - ho * p.Wo;
                 const int hi = ho * p.stride - p.pad_t + kh, wi_ = wo * p.stride - p.pad_l + kw;
-                if ((unsigned)hi < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.W)
+                if (ci0 + col4 < p.Cin && (unsigned)hi < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.W)
                     b = *reinterpret_cast<const float4 *>(p.x + (((size_t)n * p.H + hi) * p.W + wi_) * p.Cin + ci0 + col4);
             }
             ra[i] = a;
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int co = co0 + (wi * 4 + a) * 16 + 4 * kg + r;
-                out[((size_t)co * p.Cin + ci) * p.KHW + tap] = acc[a][b][r];
+                if (co < p.Cout && ci < p.Cin) out[((size_t)co * p.Cin + ci) * p.KHW + tap] = acc[a][b][r];
             }
         }
 }
@@ -190,7 +193,7 @@ using namespace cer;
 
 extern "C" size_t cer_conv2d_wgrad_b3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW) {
     if (N <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
-    const int splits = wgrad_b3_splits((long long)N * Ho * Wo, (Cout / 128) * (Cin / 128), KH * KW);
+    const int splits = wgrad_b3_splits((long long)N * Ho * Wo, ((Cout + 127) / 128) * ((Cin + 127) / 128), KH * KW);
     return splits > 1 ? (size_t)splits * Cout * Cin * KH * KW * sizeof(float) : 0;
 }
 
@@ -200,9 +203,9 @@ extern "C" int cer_conv2d_wgrad_b3(const float *dz, const float *x, float *dw, i
     if (!dz || !x || !dw || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 ||
         stride <= 0 || pad_t < 0 || pad_l < 0 || (long long)N * Ho * Wo >= (1ll << 31) || KH * KW > 65535)
         return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_wgrad_b3: bad argument");
-    if ((Cout & 127) || (Cin & 127))
-        return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d_wgrad_b3: Cout and Cin must be multiples of 128 (use cer_conv2d_wgrad)");
-    const int R = N * Ho * Wo, tiles = (Cout / 128) * (Cin / 128), taps = KH * KW;
+    if ((Cout & 3) || (Cin & 3))
+        return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d_wgrad_b3: Cout and Cin must be multiples of 4 (use cer_conv2d_wgrad)");
+    const int R = N * Ho * Wo, tiles = ((Cout + 127) / 128) * ((Cin + 127) / 128), taps = KH * KW;
     const int splits = wgrad_b3_splits(R, tiles, taps);
     const size_t n = (size_t)Cout * Cin * taps;
     if (splits > 1 && (!workspace || workspace_bytes < (size_t)splits * n * sizeof(float)))

@@ -461,14 +461,14 @@ def l2norm_rows(x):
 
 def conv2d_wgrad(dz, x, kh, kw, stride=1, pad=(0, 0), b3=False):
     """dW [Cout,Cin,KH,KW] (torch layout) from dz [N,Ho,Wo,Cout] and the conv input x [N,H,W,Cin] (both dense NHWC).
-    ``b3``: the bf16x3 MFMA kernel with the pixel range split over blocks (Cout, Cin % 128 == 0; other shapes take the
+    ``b3``: the bf16x3 MFMA kernel with the pixel range split over blocks (Cout, Cin % 4 == 0; other shapes take the
     fp32-MFMA kernel either way)."""
     _dev_f32(dz, "dz")
     _dev_f32(x, "x")
     n, ho, wo, cout = dz.shape
     _, h, w, cin = x.shape
     dw = _empty((cout, cin, kh, kw), dz)
-    if b3 and cout % 128 == 0 and cin % 128 == 0:
+    if b3 and cout % 4 == 0 and cin % 4 == 0:
         lib = _lib.load()
         nbytes = lib.cer_conv2d_wgrad_b3_workspace_bytes(n, ho, wo, cout, cin, kh, kw)
         ws = _empty((nbytes // 4,), dz) if nbytes else None

@@ -143,6 +143,35 @@ class _ReleasedUnit(torch.autograd.Function):
         return (dx if need_dx else None), None, None, dg1, db1, dw1, da1, dw2, dg2, db2, dws, dgs, dbs
 
 
+class _ReleasedStem(torch.autograd.Function):
+    """``input_layer`` (Conv2d(3, 64, 3, 1, 1, bias=False) -> BatchNorm2d -> PReLU, arcface_model.py:130-132) in train mode with
+    its backward: the last piece of a backward through the WHOLE encoder (BASELINE configs[1]; the reference's own release
+    schedule stops at half of stage 3).  The conv is the NCHW-reading fp32 kernel; its weight gradient runs on the bf16x3
+    matrix-core kernel over a 4-channel NHWC copy of the frames (no data gradient: the frames need none)."""
+
+    @staticmethod
+    def forward(ctx, x, bn, w, g, b, a):
+        n, _, h, wd = x.shape
+        z = ops.conv2d(x.contiguous(), ops.pack_conv_weight(w.detach().contiguous()), 3, 3, pad=(1, 1), x_nchw=True)
+        zb, sm, si = ops.bn_rows_fwd(z.view(-1, 64), g.detach(), b.detach(), bn.running_mean, bn.running_var, True, bn.eps,
+                                     bn.momentum)
+        zb = zb.view(n, h, wd, 64)
+        y = ops.prelu_fwd(zb, a.detach().contiguous())
+        ctx.save_for_backward(x, z, zb, sm, si, g.detach(), a.detach())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, z, zb, sm, si, g, a = ctx.saved_tensors
+        n, _, h, wd = x.shape
+        dzb, da = ops.prelu_bwd(dy.contiguous(), zb, a.contiguous())
+        dz, dg, db = ops.bn_rows_bwd(dzb.view(-1, 64), z.view(-1, 64), sm, si, g)
+        x4 = torch.zeros((n, h, wd, 4), device=x.device, dtype=torch.float32)
+        x4[..., :3] = x.permute(0, 2, 3, 1)
+        dw = ops.conv2d_wgrad(dz.view(n, h, wd, 64), x4, 3, 3, stride=1, pad=(1, 1), b3=True)[:, :3].contiguous()
+        return None, None, dw, dg, db, da
+
+
 class _ReleasedHead(torch.autograd.Function):
     """Forward + backward of the encoder's output layer in train mode, for the FIRST group of the reference's gradual
     release (base/parameter_control.py:55-103: parameters 4..9 of the visual encoder = ``output_layer``:
@@ -465,14 +494,18 @@ class IR50(nn.Module):
         P = self.pack_train_n16(dtype)
         self._packed = self._packed_b3 = self._packed_n16 = None  # running statistics are about to change
         n = x.shape[0]
-        r = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True, want_f32=False, out_n16=dtype)
-        s, t = self._finalize(r["stats"], r["n16"].numel() // 64, self.input_layer[1])
-        r = ops.bn_apply_nhwc_n16(r["n16"], s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True)
-        ys, xst = r["n16"], r["stats"]
-        del r
         plan = self._release_plan()
         first_released = len(P["units"]) if plan is None else plan
-        y = None
+        y = ys = xst = None
+        if plan is not None and self._stem_released():
+            y = self._released_stem(x)
+        else:
+            r = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True, want_f32=False, out_n16=dtype)
+            s, t = self._finalize(r["stats"], r["n16"].numel() // 64, self.input_layer[1])
+            r = ops.bn_apply_nhwc_n16(r["n16"], s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True,
+                                      out_f32=first_released == 0, out_n16=first_released != 0)
+            ys, xst, y = r.get("n16"), r["stats"], r.get("y")
+            del r
         for i, (u, d) in enumerate(zip(self.body, P["units"])):
             if i >= first_released:  # released for training: fp32 tensors, convs in this mode's arithmetic, with a backward
                 y = self._released_unit(u, y, "fp16" if dtype == torch.float16 else "bf16")
@@ -552,14 +585,18 @@ class IR50(nn.Module):
         P = self.pack_train_b3()
         self._packed = self._packed_b3 = self._packed_n16 = None  # running statistics are about to change
         n = x.shape[0]
-        y0, st = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True)
-        s, t = self._finalize(st, y0.numel() // 64, self.input_layer[1])
-        r = ops.bn_apply_nhwc_b3(y0, s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True)
-        ys, xst = r["split"], r["stats"]
-        del y0, r
         plan = self._release_plan()
         first_released = len(P["units"]) if plan is None else plan
-        y = None
+        y = ys = xst = None
+        if plan is not None and self._stem_released():
+            y = self._released_stem(x)
+        else:
+            y0, st = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True)
+            s, t = self._finalize(st, y0.numel() // 64, self.input_layer[1])
+            r = ops.bn_apply_nhwc_b3(y0, s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True,
+                                     out_f32=first_released == 0, out_split=first_released != 0)
+            ys, xst, y = r.get("split"), r["stats"], r.get("y")
+            del y0, r
         for i, (u, d) in enumerate(zip(self.body, P["units"])):
             if i >= first_released:  # released for training: fp32 tensors, bf16x3 forward / data-gradient convs, with a backward
                 y = self._released_unit(u, y, "bf16x3")
@@ -612,19 +649,21 @@ class IR50(nn.Module):
         """base/parameter_control.py:85-96 flips ``requires_grad`` of parameter groups of the visual encoder: group 1
         (indices 4..9) is exactly ``output_layer``; groups 2 and 3 are stage 4 and the second half of stage 3, i.e. always
         a SUFFIX of the body.  Returns None (nothing released / no autograd) or the index of the first released body
-        unit (len(body) when only the head is released).  Anything else fails loudly."""
+        unit (len(body) when only the head is released; 0 = the whole body, the extension BASELINE configs[1] asks for, with
+        or without the input layer).  Anything else fails loudly."""
         if not torch.is_grad_enabled():
             return None
         head = [p.requires_grad for p in self.output_layer.parameters()]
-        if any(p.requires_grad for p in self.input_layer.parameters()):
-            raise NotImplementedError("releasing the stem is not supported: the released units must be a suffix of the body")
+        stem = [p.requires_grad for p in self.input_layer.parameters()]
+        if any(stem) and not all(stem):
+            raise NotImplementedError("release the whole input layer (conv, BatchNorm, PReLU) or nothing")
         flags = []
         for u in self.body:
             f = [p.requires_grad for p in u.parameters()]
             if any(f) and not all(f):
                 raise NotImplementedError("release whole units (all parameters of a bottleneck_IR unit) or nothing")
             flags.append(all(f))
-        if not any(head) and not any(flags):
+        if not any(head) and not any(flags) and not any(stem):
             return None
         if not all(head):
             raise NotImplementedError("release the whole output layer (parameters 4..9) first, as the reference does")
@@ -633,9 +672,16 @@ class IR50(nn.Module):
             first -= 1
         if any(flags[:first]):
             raise NotImplementedError("released body units must form a suffix of the body (the reference releases from the top)")
-        if first == 0:
-            raise NotImplementedError("the first unit stays frozen (the reference never releases below half of stage 3)")
+        if all(stem) and first != 0:
+            raise NotImplementedError("the input layer can only be released together with the whole body (gradients flow top-down)")
         return first
+
+    def _stem_released(self):
+        return torch.is_grad_enabled() and all(p.requires_grad for p in self.input_layer.parameters())
+
+    def _released_stem(self, x):
+        il = self.input_layer
+        return _ReleasedStem.apply(x, il[1], il[0].weight, il[1].weight, il[1].bias, il[2].weight)
 
     @staticmethod
     def _released_unit(u, y, prec="fp32"):
@@ -668,12 +714,16 @@ class IR50(nn.Module):
         P = self.pack_train()
         self._packed = self._packed_b3 = self._packed_n16 = None  # running statistics are about to change: folded eval weights go stale
         n = x.shape[0]
-        y0, st = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True)
-        s, t = self._finalize(st, y0.numel() // 64, self.input_layer[1])
-        y, xst = ops.bn_apply_nhwc(y0, s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True)
-        del y0
         plan = self._release_plan()
         first_released = len(P["units"]) if plan is None else plan
+        xst = None
+        if plan is not None and self._stem_released():
+            y = self._released_stem(x)
+        else:
+            y0, st = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True)
+            s, t = self._finalize(st, y0.numel() // 64, self.input_layer[1])
+            y, xst = ops.bn_apply_nhwc(y0, s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True)
+            del y0
         for i, (u, d) in enumerate(zip(self.body, P["units"])):
             if i >= first_released:
                 y = self._released_unit(u, y)

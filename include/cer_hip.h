@@ -211,8 +211,9 @@ int cer_conv2d_wgrad(const float *dz, const float *x, float *dw, int N, int H, i
 /* The same on the bf16 matrix cores with split hi/lo operands ("bf16x3": three MFMAs per product, <= 2^-15 relative per
  * product, fp32 accumulation), the pixel range split over blocks and reduced in a fixed order: the weight gradient of the
  * reference's released encoder units (base/parameter_control.py:55-103 un-freezes IR-50 stage 4 and half of stage 3; their
- * backward is torch autograd's conv2d weight gradient, models/arcface_model.py:44-60).  Cout and Cin must be multiples of 128
- * (CER_ERR_UNSUPPORTED otherwise: use cer_conv2d_wgrad). */
+ * backward is torch autograd's conv2d weight gradient, models/arcface_model.py:44-60).  Cout and Cin must be multiples of 4
+ * (CER_ERR_UNSUPPORTED otherwise: use cer_conv2d_wgrad); the output tile is 128 x 128, so channel counts below 128 waste
+ * matrix-core work but stay correct. */
 size_t cer_conv2d_wgrad_b3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW);
 int cer_conv2d_wgrad_b3(const float *dz, const float *x, float *dw, int N, int H, int W, int Ho, int Wo, int Cout, int Cin,
                         int KH, int KW, int stride, int pad_t, int pad_l, void *workspace, size_t workspace_bytes, void *stream);

@@ -58,8 +58,18 @@ def test_released_head_matches_reference_step():
 
 def test_release_of_a_non_suffix_fails_loudly():
     g, vb, frames, G = _setup()
-    vb.train()  # every parameter still requires grad, the stem included: not a suffix of the body
+    for p in vb.parameters():
+        p.requires_grad = False
+    for p in list(vb.backbone.output_layer.parameters()) + list(vb.backbone.body[5].parameters()):
+        p.requires_grad = True         # a unit in the middle of the body: gradients would have to cross frozen units above it
+    vb.train()
     with pytest.raises(NotImplementedError, match="suffix of the body"):
+        vb(frames.cuda())
+    for p in vb.backbone.body[5].parameters():
+        p.requires_grad = False
+    for p in vb.backbone.input_layer.parameters():
+        p.requires_grad = True         # the stem without the body above it
+    with pytest.raises(NotImplementedError, match="together with the whole body"):
         vb(frames.cuda())
 
 
@@ -173,9 +183,79 @@ def test_conv2d_wgrad_and_dgrad_vs_autograd(n, cin, cout, hw, k, stride):
     assert (dx.cpu().permute(0, 3, 1, 2) - x.grad).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize("precision,with_stem", [("fp32", True), ("bf16x3", True), ("bf16x3", False)])
+def test_whole_encoder_backward_vs_float64_oracle(precision, with_stem):
+    """BASELINE configs[1] ("IR-ResNet50 forward+backward"): every unit of the body (and the input layer) released -- an
+    extension of the reference's schedule, which stops at half of stage 3 -- against torch autograd through the float64
+    oracle (oracle/ir50.py, itself pinned to the reference's VisualBackbone) on the same frames, weights and head dropout
+    mask.  Gradients are compared per parameter in relative L2 (an element-wise bound is ill posed: a PReLU pre-activation
+    within rounding of zero flips its derivative, see test_released_stage4_matches_reference_step) and as one vector."""
+    import oracle.ir50 as oracle_ir50
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.visual_backbone import VisualBackbone
+    n, hw = 8, 40
+    vsd = synth.make_state_dict(synth.visual_backbone_spec("", hw // 8), seed=21)
+    gen = torch.Generator().manual_seed(22)
+    frames = torch.randn(n, 3, hw, hw, generator=gen)
+    G = torch.randn(n, 512, generator=gen)
+    keep = (torch.rand(n, 512, hw // 8, hw // 8, generator=gen) >= 0.4).double() / 0.6
+    # float64 reference
+    sd64 = {k[len("backbone."):]: v.double().clone() for k, v in vsd.items() if k.startswith("backbone.")}
+    train_keys = [k for k in sd64 if not k.endswith(("running_mean", "running_var", "num_batches_tracked")) and
+                  (with_stem or not k.startswith("input_layer."))]
+    for k in train_keys:
+        sd64[k].requires_grad_(True)
+    emb64 = oracle_ir50.ir50_forward(frames.double(), sd64, train=True, head_dropout_mask=keep)
+    (emb64 * G.double()).sum().backward()
+    # HIP
+    vb = VisualBackbone(use_pretrained=False, head_hw=hw // 8)
+    vb.load_state_dict(vsd, strict=True)
+    vb = vb.cuda()
+    vb.backbone.precision = precision
+    for p_ in vb.parameters():
+        p_.requires_grad = False
+    named = dict(vb.backbone.named_parameters())
+    for k in train_keys:
+        named[k].requires_grad = True
+    vb.train()
+    emb = vb(frames.cuda(), keep.float().permute(0, 2, 3, 1).contiguous().cuda())
+    assert (emb.detach().cpu().double() - emb64.detach()).abs().max().item() < (1e-5 if precision == "fp32" else 1e-4)
+    (emb * G.cuda()).sum().backward()
+    if not with_stem:
+        assert all(named[k].grad is None for k in named if k.startswith("input_layer."))
+    # yardstick: torch's own float32 autograd through the same oracle -- how far plain fp32 arithmetic lands from float64 on
+    # this 24-unit, batch-statistics, 8-frame problem
+    sd32 = {k: v.detach().float().clone() for k, v in sd64.items()}
+    for k in train_keys:
+        sd32[k].requires_grad_(True)
+    (oracle_ir50.ir50_forward(frames, sd32, train=True, head_dropout_mask=keep.float()) * G).sum().backward()
+
+    def errors(grad_of):
+        num = den = 0.0
+        worst = (0.0, "")
+        for k in train_keys:
+            ref, got = sd64[k].grad, grad_of(k)
+            assert got.shape == ref.shape, k
+            d, r = (got - ref).norm().item(), ref.norm().item()
+            num, den = num + d * d, den + r * r
+            if r > 1e-6:
+                worst = max(worst, (d / r, k))
+        return worst, (num / den) ** 0.5
+
+    worst32, all32 = errors(lambda k: sd32[k].grad.double())
+    worst, allv = errors(lambda k: named[k].grad.detach().cpu().double())
+    print(f"whole-encoder backward [{precision}]: worst per-parameter rel L2 {worst[0]:.2e} ({worst[1]}), all gradients {allv:.2e}; "
+          f"torch fp32: {worst32[0]:.2e} ({worst32[1]}), {all32:.2e}")
+    factor = 4.0 if precision == "fp32" else 16.0   # bf16x3: 2^-15 per product against fp32's 2^-24 accumulation noise
+    assert worst[0] < factor * worst32[0] + 1e-4, (worst, worst32)
+    assert allv < factor * all32 + 1e-5, (allv, all32)
+
+
 @pytest.mark.parametrize("n,cin,cout,hw,k,stride,prec", [
     (40, 128, 128, 10, 3, 1, "bf16x3"), (300, 256, 128, 5, 3, 1, "bf16x3"), (37, 128, 256, 10, 3, 2, "bf16x3"),
-    (50, 128, 256, 9, 1, 2, "bf16x3"), (3, 128, 128, 7, 3, 1, "bf16x3"), (40, 128, 128, 10, 3, 1, "fp16")])
+    (50, 128, 256, 9, 1, 2, "bf16x3"), (3, 128, 128, 7, 3, 1, "bf16x3"), (40, 128, 128, 10, 3, 1, "fp16"),
+    # channel counts below the 128 x 128 output tile (stage 1 / 2 layers, the 3 -> 4 channel stem)
+    (9, 64, 64, 12, 3, 1, "bf16x3"), (9, 64, 128, 12, 3, 2, "bf16x3"), (5, 4, 64, 20, 3, 1, "bf16x3")])
 def test_conv2d_wgrad_b3_and_dgrad_in_the_encoder_precision(n, cin, cout, hw, k, stride, prec):
     """The matrix-core weight gradient (transposed LDS reads, split operands, pixel range split over blocks and reduced in a
     fixed order) and the data gradient on the bf16x3 / narrow conv kernels, against float64 autograd.  Error model: every
