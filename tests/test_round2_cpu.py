@@ -33,6 +33,62 @@ def test_lds_swizzles_are_conflict_free_under_the_ds_read_b128_bank_model():
     assert sum(f << (2 * i) for i, f in enumerate(cs.B3_PATCH_F)) == 0xaaa00a00
     # a linear (unswizzled) image of 128-byte rows is a 4-way conflict: the model does discriminate
     assert cs.worst_way(lambda l: (l & 15) * 128 + ((l >> 4) << 4)) == 4
+    # 1-D window kernels: fragment rows start at ANY row (tap shift kh * W + kw for arbitrary W): one swizzle per row width
+    for first_row in range(64):
+        assert cs.worst_way(lambda l: cs.b3_win_fragment_addr(l, first_row)) == 1
+        for kk in (0, 1):
+            assert cs.worst_way(lambda l: cs.n16_win_fragment_addr(l, first_row, kk)) == 1
+
+
+def test_release_plan_accepts_suffixes_of_the_body_and_fails_loudly_otherwise():
+    """IR50._release_plan only reads requires_grad flags: the reference's three release groups, the whole-encoder extension
+    (BASELINE configs[1]) and the rejected combinations, without a GPU."""
+    import pytest
+    import torch
+    from feature_vs_text_compound_emotion_amd.parameter_control import ResnetParamControl
+    from feature_vs_text_compound_emotion_amd.visual_backbone import VisualBackbone
+    vb = VisualBackbone(use_pretrained=False, head_hw=5)
+    bb = vb.backbone
+
+    def freeze():
+        for p in vb.parameters():
+            p.requires_grad = False
+
+    freeze()
+    assert bb._release_plan() is None
+    pc = ResnetParamControl(trainer=None, release_count=3)
+    expect = [24, 21, 18]          # head only; + stage 4 (units 21-23); + the last three units of stage 3 (parameters 142..162)
+    for first in expect:
+        pc.release_param({"visual": vb})
+        assert bb._release_plan() == first
+        assert not bb._stem_released()
+    for p in bb.body.parameters():
+        p.requires_grad = True
+    assert bb._release_plan() == 0 and not bb._stem_released()
+    for p in bb.input_layer.parameters():
+        p.requires_grad = True
+    assert bb._release_plan() == 0 and bb._stem_released()
+    with torch.no_grad():
+        assert bb._release_plan() is None and not bb._stem_released()
+    freeze()
+    for p in list(bb.output_layer.parameters()) + list(bb.body[5].parameters()):
+        p.requires_grad = True
+    with pytest.raises(NotImplementedError, match="suffix of the body"):
+        bb._release_plan()
+    freeze()
+    for p in list(bb.output_layer.parameters()) + list(bb.input_layer.parameters()):
+        p.requires_grad = True
+    with pytest.raises(NotImplementedError, match="together with the whole body"):
+        bb._release_plan()
+    freeze()
+    bb.body[23].res_layer[1].weight.requires_grad = True
+    with pytest.raises(NotImplementedError, match="whole units"):
+        bb._release_plan()
+    freeze()
+    for p in bb.body[23].parameters():
+        p.requires_grad = True
+    with pytest.raises(NotImplementedError, match="whole output layer"):
+        bb._release_plan()
 
 
 def test_scores_from_confusion_counts_equal_the_label_list_definitions():
