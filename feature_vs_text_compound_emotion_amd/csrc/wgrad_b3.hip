@@ -38,26 +38,33 @@ struct Wgrad2dArgs {
 
 __device__ __forceinline__ int wg_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
 
+// TS = output tile edge: 128 (wave = 64 x 64 = 4 x 4 MFMA tiles) or 64 (wave = 32 x 32: the 64-channel layers and the stem
+// without the 2-4x of zero columns a 128-wide tile would multiply)
+template <int TS>
 __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) {
     constexpr int KS = 32, PLANE = KS * 256, STAGE = 4 * PLANE;       // planes per stage: dZ hi, dZ lo, X hi, X lo
+    constexpr int NTW = TS / 32;                                      // 16-wide MFMA tiles per wave and side
+    constexpr int LPT = TS / 32;                                      // float4 loads per thread, operand and step
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
     const int kg = lane >> 4, l15 = lane & 15;
-    const int tiles_ci = (p.Cin + 127) / 128;
-    const int co0 = (blockIdx.x / tiles_ci) * 128, ci0 = (blockIdx.x % tiles_ci) * 128;
+    const int tiles_ci = (p.Cin + TS - 1) / TS;
+    const int co0 = (blockIdx.x / tiles_ci) * TS, ci0 = (blockIdx.x % tiles_ci) * TS;
     const int tap = blockIdx.y, kh = tap / p.KW, kw = tap - kh * p.KW;
     const int r_begin = blockIdx.z * p.rows_per_split;
     const int r_end = min(p.R, r_begin + p.rows_per_split);
 
     // ---- loader: thread = 4 consecutive channels of rows lrow + 8 i ----
-    const int col4 = (tid & 31) * 4, lrow = tid >> 5;
+    constexpr int TPR = TS / 4;                                       // threads per row
+    const int col4 = (tid % TPR) * 4, lrow = tid / TPR;               // rows lrow + (256 / TPR) i
+    constexpr int RSTEP = 256 / TPR;
     const int hw = p.Ho * p.Wo;
-    float4 ra[4], rb[4];
+    float4 ra[LPT], rb[LPT];
     auto load_step = [&](int r0) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = r0 + lrow + 8 * i;
+        for (int i = 0; i < LPT; ++i) {
+            const int r = r0 + lrow + RSTEP * i;
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < r_end) {
                 // (channel counts are multiples of 4; columns past Cout / Cin stay zero: 64-channel layers and the 3 -> 4
@@ -76,8 +83,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
     auto store_step = [&](int buf) {
         unsigned char *base = smem + buf * STAGE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int row = lrow + 8 * i;
+        for (int i = 0; i < LPT; ++i) {
+            const int row = lrow + RSTEP * i;
             const int byte = wg_off(row, col4 >> 3) + 8 * ((col4 >> 2) & 1);
             const float va[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w}, vb[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
             ushort4 h, l;
@@ -93,14 +100,14 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
     // ---- transposed operand reads: lane 4q + p of a 16-lane group supplies row r0 + q, columns 4p .. 4p+3 of the block;
     // group kg reads rows 8 kg .. 8 kg + 3 and 8 kg + 4 .. 8 kg + 7 (the 8 pixels of its k group) ----
     const int q4 = l15 >> 2, p4 = l15 & 3;
-    int tr_a[4][2], tr_b[4][2];   // byte offsets inside a plane: [16-channel tile of this wave][row half]
+    int tr_a[NTW][2], tr_b[NTW][2];   // byte offsets inside a plane: [16-channel tile of this wave][row half]
 #pragma unroll
-    for (int t = 0; t < 4; ++t)
+    for (int t = 0; t < NTW; ++t)
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const int row = 8 * kg + 4 * h + q4;
-            tr_a[t][h] = wg_off(row, 2 * (wi * 4 + t) + (p4 >> 1)) + 8 * (p4 & 1);
-            tr_b[t][h] = wg_off(row, 2 * (wj * 4 + t) + (p4 >> 1)) + 8 * (p4 & 1);
+            tr_a[t][h] = wg_off(row, 2 * (wi * NTW + t) + (p4 >> 1)) + 8 * (p4 & 1);
+            tr_b[t][h] = wg_off(row, 2 * (wj * NTW + t) + (p4 >> 1)) + 8 * (p4 & 1);
         }
     // (fragments travel as short vectors and are re-typed at the MFMA: a lambda returning a __bf16 vector made hipcc's host
     // pass drop the kernel stub, see conv_b3_patch.hip)
@@ -111,11 +118,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
         return v;
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[NTW][NTW];
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NTW; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b)
+        for (int b = 0; b < NTW; ++b)
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
 
@@ -129,26 +136,26 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
         const int buf = s & 1;
         if (s + 1 < steps) load_step(r_begin + (s + 1) * KS);
         const unsigned char *base = smem + buf * STAGE;
-        s16x8 ah[4], al[4], bh[4], bl[4];
+        s16x8 ah[NTW], al[NTW], bh[NTW], bl[NTW];
 #pragma unroll
-        for (int t = 0; t < 4; ++t) {
+        for (int t = 0; t < NTW; ++t) {
             ah[t] = frag(base, tr_a[t]);
             al[t] = frag(base + PLANE, tr_a[t]);
             bh[t] = frag(base + 2 * PLANE, tr_b[t]);
             bl[t] = frag(base + 3 * PLANE, tr_b[t]);
         }
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < NTW; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(al[a]), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
+            for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(al[a]), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < NTW; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah[a]), as_bf16(bl[b]), acc[a][b], 0, 0, 0);
+            for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah[a]), as_bf16(bl[b]), acc[a][b], 0, 0, 0);
 #pragma unroll
-        for (int a = 0; a < 4; ++a)
+        for (int a = 0; a < NTW; ++a)
 #pragma unroll
-            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah[a]), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
+            for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah[a]), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
         if (s + 1 < steps) store_step(buf ^ 1);
         __syncthreads();
     }
@@ -156,13 +163,13 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
     // D[i = cout][j = cin]: lane -> cin (l15), register r -> cout 4 kg + r
     float *out = p.out + (size_t)blockIdx.z * p.Cout * p.Cin * p.KHW;
 #pragma unroll
-    for (int a = 0; a < 4; ++a)
+    for (int a = 0; a < NTW; ++a)
 #pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const int ci = ci0 + (wj * 4 + b) * 16 + l15;
+        for (int b = 0; b < NTW; ++b) {
+            const int ci = ci0 + (wj * NTW + b) * 16 + l15;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int co = co0 + (wi * 4 + a) * 16 + 4 * kg + r;
+                const int co = co0 + (wi * NTW + a) * 16 + 4 * kg + r;
                 if (co < p.Cout && ci < p.Cin) out[((size_t)co * p.Cin + ci) * p.KHW + tap] = acc[a][b][r];
             }
         }
@@ -191,9 +198,13 @@ static int wgrad_b3_splits(long long R, int tiles, int taps) {
 
 using namespace cer;
 
+// 64 x 64 tiles when a 128-wide tile would be at most half full on either side
+static int wgrad_b3_tile(int Cout, int Cin) { return (Cout <= 64 || Cin <= 64) ? 64 : 128; }
+
 extern "C" size_t cer_conv2d_wgrad_b3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW) {
     if (N <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
-    const int splits = wgrad_b3_splits((long long)N * Ho * Wo, ((Cout + 127) / 128) * ((Cin + 127) / 128), KH * KW);
+    const int ts = wgrad_b3_tile(Cout, Cin);
+    const int splits = wgrad_b3_splits((long long)N * Ho * Wo, ((Cout + ts - 1) / ts) * ((Cin + ts - 1) / ts), KH * KW);
     return splits > 1 ? (size_t)splits * Cout * Cin * KH * KW * sizeof(float) : 0;
 }
 
@@ -205,14 +216,16 @@ extern "C" int cer_conv2d_wgrad_b3(const float *dz, const float *x, float *dw, i
         return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_wgrad_b3: bad argument");
     if ((Cout & 3) || (Cin & 3))
         return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d_wgrad_b3: Cout and Cin must be multiples of 4 (use cer_conv2d_wgrad)");
-    const int R = N * Ho * Wo, tiles = ((Cout + 127) / 128) * ((Cin + 127) / 128), taps = KH * KW;
+    const int ts = wgrad_b3_tile(Cout, Cin);
+    const int R = N * Ho * Wo, tiles = ((Cout + ts - 1) / ts) * ((Cin + ts - 1) / ts), taps = KH * KW;
     const int splits = wgrad_b3_splits(R, tiles, taps);
     const size_t n = (size_t)Cout * Cin * taps;
     if (splits > 1 && (!workspace || workspace_bytes < (size_t)splits * n * sizeof(float)))
         return cer_set_error(CER_ERR_WORKSPACE, "conv2d_wgrad_b3: workspace too small");
     Wgrad2dArgs a{dz, x, splits > 1 ? (float *)workspace : dw, R, Cout, Cin, taps, KW, H, W, Ho, Wo, stride, pad_t, pad_l, 0};
     a.rows_per_split = ((R + splits - 1) / splits + 31) / 32 * 32;
-    CER_LAUNCH(conv2d_wgrad_b3_kernel, dim3(tiles, taps, splits), dim3(256), 0, (hipStream_t)stream, a);
+    if (ts == 64) CER_LAUNCH(conv2d_wgrad_b3_kernel<64>, dim3(tiles, taps, splits), dim3(256), 0, (hipStream_t)stream, a);
+    else CER_LAUNCH(conv2d_wgrad_b3_kernel<128>, dim3(tiles, taps, splits), dim3(256), 0, (hipStream_t)stream, a);
     if (splits > 1)
         CER_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                    (const float4 *)workspace, (float4 *)dw, n / 4, splits);
