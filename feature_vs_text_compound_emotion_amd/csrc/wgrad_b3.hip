@@ -42,7 +42,7 @@ __device__ __forceinline__ int wg_off(int row, int ch) { return 256 * row + 16 *
 // without the 2-4x of zero columns a 128-wide tile would multiply)
 template <int TS>
 __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) {
-    constexpr int KS = 32, PLANE = KS * 256, STAGE = 4 * PLANE;       // planes per stage: dZ hi, dZ lo, X hi, X lo
+    constexpr int KS = 32, KS32 = 32, PLANE = KS * 256, STAGE = 4 * PLANE;   // planes per stage: dZ hi, dZ lo, X hi, X lo
     constexpr int NTW = TS / 32;                                      // 16-wide MFMA tiles per wave and side
     constexpr int LPT = TS / 32;                                      // float4 loads per thread, operand and step
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
@@ -61,6 +61,18 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
     constexpr int RSTEP = 256 / TPR;
     const int hw = p.Ho * p.Wo;
     float4 ra[LPT], rb[LPT];
+    // (n, ho, wo) of this thread's rows, advanced by the 32 rows of a step without divisions (the index arithmetic of the
+    // loader was half of the wave's issue slots: PMC "active" 51 % at MFMA busy 23 %)
+    int pn[LPT], pho[LPT], pwo[LPT];
+#pragma unroll
+    for (int i = 0; i < LPT; ++i) {
+        const int r = r_begin + lrow + RSTEP * i;
+        pn[i] = r / hw;
+        const int q = r - pn[i] * hw;
+        pho[i] = q / p.Wo;
+        pwo[i] = q - pho[i] * p.Wo;
+    }
+    const int adv_h = KS32 / p.Wo, adv_w = KS32 - adv_h * p.Wo;
     auto load_step = [&](int r0) {
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
@@ -68,16 +80,24 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
             float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < r_end) {
                 // (channel counts are multiples of 4; columns past Cout / Cin stay zero: 64-channel layers and the 3 -> 4
-                // channel stem use part of the 128 x 128 tile)
+                // channel stem use part of the tile)
                 if (co0 + col4 < p.Cout) a = *reinterpret_cast<const float4 *>(p.dz + (size_t)r * p.Cout + co0 + col4);
-                const int n = r / hw, q = r - n * hw;
-                const int ho = q / p.Wo, wo = q - ho * p.Wo;
-                const int hi = ho * p.stride - p.pad_t + kh, wi_ = wo * p.stride - p.pad_l + kw;
+                const int hi = pho[i] * p.stride - p.pad_t + kh, wi_ = pwo[i] * p.stride - p.pad_l + kw;
                 if (ci0 + col4 < p.Cin && (unsigned)hi < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.W)
-                    b = *reinterpret_cast<const float4 *>(p.x + (((size_t)n * p.H + hi) * p.W + wi_) * p.Cin + ci0 + col4);
+                    b = *reinterpret_cast<const float4 *>(p.x + (((size_t)pn[i] * p.H + hi) * p.W + wi_) * p.Cin + ci0 + col4);
             }
             ra[i] = a;
             rb[i] = b;
+            pwo[i] += adv_w;
+            pho[i] += adv_h;
+            if (pwo[i] >= p.Wo) {
+                pwo[i] -= p.Wo;
+                ++pho[i];
+            }
+            while (pho[i] >= p.Ho) {
+                pho[i] -= p.Ho;
+                ++pn[i];
+            }
         }
     };
     auto store_step = [&](int buf) {

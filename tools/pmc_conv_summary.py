@@ -11,7 +11,7 @@ n = defaultdict(int)
 dur = defaultdict(float)
 for f in glob.glob(sys.argv[1] + "/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        if "conv_" not in r["Kernel_Name"] or "pack_conv" in r["Kernel_Name"]:
+        if ("conv_" not in r["Kernel_Name"] and "wgrad" not in r["Kernel_Name"]) or "pack_conv" in r["Kernel_Name"]:
             continue
         k = r["Kernel_Name"].split("(")[0].replace("void ", "")
         acc[k][r["Counter_Name"]] += float(r["Counter_Value"])
