@@ -34,6 +34,7 @@ struct Wgrad2dArgs {
     float *out;          // dw, or the partial slabs [splits][Cout * Cin * KH * KW]
     int R, Cout, Cin, KHW, KW, H, W, Ho, Wo, stride, pad_t, pad_l;
     int rows_per_split;  // multiple of 32
+    int tiles, splits;   // output tiles per tap, row splits
 };
 
 __device__ __forceinline__ int wg_off(int row, int ch) { return 256 * row + 16 * (ch ^ (((row & 3) << 2) | ((row >> 2) & 3))); }
@@ -49,10 +50,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave & 1, wj = wave >> 1;
     const int kg = lane >> 4, l15 = lane & 15;
+    // XCD-aware work order: the tiles x taps blocks of one row split all read the same dZ / X rows (a few MiB), so they are
+    // given to ONE XCD (block b runs on XCD b % 8) and hit its L2; dealt tile-major the same rows were fetched by all eight
+    // L2s and the kernel sat at the HBM roof (3.8 GB per 256 -> 256 launch at 5.9 TB/s)
+    const int per = p.tiles * p.KHW;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int split = (j / per) * 8 + xcd, within = j % per;
+    if (split >= p.splits) return;
+    const int tile = within % p.tiles, tap = within / p.tiles, kh = tap / p.KW, kw = tap - kh * p.KW;
     const int tiles_ci = (p.Cin + TS - 1) / TS;
-    const int co0 = (blockIdx.x / tiles_ci) * TS, ci0 = (blockIdx.x % tiles_ci) * TS;
-    const int tap = blockIdx.y, kh = tap / p.KW, kw = tap - kh * p.KW;
-    const int r_begin = blockIdx.z * p.rows_per_split;
+    const int co0 = (tile / tiles_ci) * TS, ci0 = (tile % tiles_ci) * TS;
+    const int r_begin = split * p.rows_per_split;
     const int r_end = min(p.R, r_begin + p.rows_per_split);
 
     // ---- loader: thread = 4 consecutive channels of rows lrow + 8 i ----
@@ -181,7 +189,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
     }
 
     // D[i = cout][j = cin]: lane -> cin (l15), register r -> cout 4 kg + r
-    float *out = p.out + (size_t)blockIdx.z * p.Cout * p.Cin * p.KHW;
+    float *out = p.out + (size_t)split * p.Cout * p.Cin * p.KHW;
 #pragma unroll
     for (int a = 0; a < NTW; ++a)
 #pragma unroll
@@ -209,6 +217,7 @@ __global__ void wgrad_reduce_kernel(const float4 *__restrict__ part, float4 *__r
 static int wgrad_b3_splits(long long R, int tiles, int taps) {
     // enough blocks for two waves of 512 resident blocks, at least 8 K steps each
     long long s = (1024 + (long long)tiles * taps - 1) / ((long long)tiles * taps);
+    s = (s + 7) / 8 * 8;   // one split per XCD and round (see the kernel's work order)
     const long long max_s = (R + 255) / 256;
     if (s > max_s) s = max_s;
     return (int)(s < 1 ? 1 : s);
@@ -242,10 +251,11 @@ extern "C" int cer_conv2d_wgrad_b3(const float *dz, const float *x, float *dw, i
     const size_t n = (size_t)Cout * Cin * taps;
     if (splits > 1 && (!workspace || workspace_bytes < (size_t)splits * n * sizeof(float)))
         return cer_set_error(CER_ERR_WORKSPACE, "conv2d_wgrad_b3: workspace too small");
-    Wgrad2dArgs a{dz, x, splits > 1 ? (float *)workspace : dw, R, Cout, Cin, taps, KW, H, W, Ho, Wo, stride, pad_t, pad_l, 0};
+    Wgrad2dArgs a{dz, x, splits > 1 ? (float *)workspace : dw, R, Cout, Cin, taps, KW, H, W, Ho, Wo, stride, pad_t, pad_l, 0, tiles, splits};
     a.rows_per_split = ((R + splits - 1) / splits + 31) / 32 * 32;
-    if (ts == 64) CER_LAUNCH(conv2d_wgrad_b3_kernel<64>, dim3(tiles, taps, splits), dim3(256), 0, (hipStream_t)stream, a);
-    else CER_LAUNCH(conv2d_wgrad_b3_kernel<128>, dim3(tiles, taps, splits), dim3(256), 0, (hipStream_t)stream, a);
+    const dim3 grid((unsigned)((splits + 7) / 8 * 8 * tiles * taps));
+    if (ts == 64) CER_LAUNCH(conv2d_wgrad_b3_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    else CER_LAUNCH(conv2d_wgrad_b3_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
     if (splits > 1)
         CER_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                    (const float4 *)workspace, (float4 *)dw, n / 4, splits);
