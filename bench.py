@@ -38,16 +38,12 @@ NARROW = ("bf16", "fp16")
 KERNEL_NAMES = {41: "cer::conv_b3_dma16_kernel<128, 128, 2, 2, 4, 2>", 42: "cer::conv_b3_dma16_kernel<128, 64, 2, 2, 4, 2>",
                 44: "cer::conv_b3_dma16_kernel<64, 128, 1, 4, 4, 2>", 45: "cer::conv_b3_dma16_kernel<64, 64, 2, 2, 4, 2>",
                 48: "cer::conv_b3_dma16_kernel<256, 64, 4, 1, 4, 2>",
-                51: "cer::conv_b3_patch_kernel<64, 4, 2, false>", 52: "cer::conv_b3_patch_kernel<128, 4, 2, false>",
-                53: "cer::conv_b3_win_kernel<64, 4, 2, false>", 54: "cer::conv_b3_win_kernel<128, 4, 2, false>",
-                55: "cer::conv_b3_win_kernel<64, 4, 2, true>", 56: "cer::conv_b3_win_kernel<128, 4, 2, true>",
-                57: "cer::conv_b3_patch_kernel<64, 4, 2, true>", 58: "cer::conv_b3_patch_kernel<128, 4, 2, true>",
+                55: "cer::conv_b3_win_kernel<64, 4, 2>", 56: "cer::conv_b3_win_kernel<128, 4, 2>",
+                57: "cer::conv_b3_patch_kernel<64, 4, 2>", 58: "cer::conv_b3_patch_kernel<128, 4, 2>",
                 71: "cer::conv_n16_patch_kernel<64, 4, 1, 1, {f16}, false>", 72: "cer::conv_n16_patch_kernel<128, 4, 2, 2, {f16}, false>",
                 78: "cer::conv_n16_patch_kernel<128, 4, 2, 2, {f16}, true>",
-                73: "cer::conv_n16_win_kernel<64, 4, 2, {f16}, false>", 74: "cer::conv_n16_win_kernel<128, 4, 2, {f16}, false>",
-                75: "cer::conv_n16_win_kernel<64, 4, 2, {f16}, true>", 76: "cer::conv_n16_win_kernel<128, 4, 2, {f16}, true>",
+                73: "cer::conv_n16_win_kernel<64, 4, 2, {f16}, false>", 76: "cer::conv_n16_win_kernel<128, 4, 2, {f16}, true>",
                 91: "cer::conv_n16_kernel<256, 256, 2, 4, {f16}, 2>", 94: "cer::conv_n16_kernel<128, 128, 2, 2, {f16}, 2>",
-                61: "cer::conv_n16_kernel<256, 256, 2, 4, {f16}, 1>", 62: "cer::conv_n16_kernel<256, 128, 4, 2, {f16}, 1>",
                 63: "cer::conv_n16_kernel<256, 64, 4, 1, {f16}, 1>", 64: "cer::conv_n16_kernel<128, 128, 2, 2, {f16}, 1>",
                 65: "cer::conv_n16_kernel<128, 64, 2, 2, {f16}, 1>", 66: "cer::conv_n16_kernel<64, 64, 2, 2, {f16}, 1>",
                 67: "cer::conv_n16_kernel<64, 128, 1, 4, {f16}, 1>"}

@@ -375,10 +375,9 @@ static int launch_b3_dma16(const ConvArgs &a, hipStream_t st) {
 }
 
 // tile ids (desc.tile): 0 auto; 41/42/44/45 = 128x128 / 128x64 / 64x128 / 64x64 (4 waves, two LDS stages);
-// 48 = 256x64 (4 waves x (64 pixels x 64 couts)) for Cout <= 64 at large M; patch kernels (conv_b3_patch.hip: 3x3 / stride 1 /
-// pad 1 on images with H, W % 16 == 0, the input window of a 16x16 output patch resident in LDS): 51 = 64 couts, 52 = 128 couts;
-// 1-D window kernels (same file: 3x3 / stride 1 / pad 1 at ANY image size with W <= 86, the input window of 256 consecutive
-// output pixels resident in LDS): 53 = 64 couts, 54 = 128 couts.
+// 48 = 256x64 (4 waves x (64 pixels x 64 couts)) for Cout <= 64 at large M; window-resident kernels (conv_b3_patch.hip, 3x3 /
+// stride 1 / pad 1): 57 / 58 = 16x16 patches x 64 / 128 couts (H, W % 16 == 0), 55 / 56 = 1-D windows of 256 consecutive
+// pixels x 64 / 128 couts (any image size with W <= 86).
 static bool b3_patch_geometry(const cer_conv_desc *d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil_h == 1 && d->dil_w == 1 && d->pad_t == 1 && d->pad_l == 1 &&
            d->Ho == d->H && d->Wo == d->W && (d->H & 15) == 0 && (d->W & 15) == 0 && (d->Cin & 31) == 0 && d->split_k <= 1;
@@ -411,10 +410,10 @@ int conv_b3_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         case 44: bm = 64; bn = 128; break;
         case 45: bm = 64; bn = 64; break;
         case 48: bm = 256; bn = 64; break;
-        case 51: case 57: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels (57 / 58: ping-pong phases)
-        case 52: case 58: bm = 256; bn = 128; break;
-        case 53: case 55: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels
-        case 54: case 56: bm = 256; bn = 128; break;   // (55 / 56: ping-pong phases)
+        case 57: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels
+        case 58: bm = 256; bn = 128; break;
+        case 55: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels
+        case 56: bm = 256; bn = 128; break;
         default: return 0;
     }
     return tile;
@@ -427,7 +426,7 @@ int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 44: return launch_b3_dma16<64, 128, 1, 4>(a, st);
         case 45: return launch_b3_dma16<64, 64, 2, 2>(a, st);
         case 48: return launch_b3_dma16<256, 64, 4, 1>(a, st);
-        case 51: case 52: case 53: case 54: case 55: case 56: case 57: case 58: return conv_b3_patch_launch(tile, a, st);
+        case 55: case 56: case 57: case 58: return conv_b3_patch_launch(tile, a, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3): unknown tile id");
     }
 }

@@ -9,8 +9,13 @@
 //     window COLUMN found by exhaustive search (tools/check_swizzle.py: B3_PATCH_F);
 //   * the weights stream: one BN x 32 slice (two planes) per (chunk, tap) through a 3-slot ring, two steps ahead, counted
 //     vmcnt; the NEXT chunk's window is fetched a whole chunk (nine steps) ahead into the second window buffer;
-//   * a * b = a_hi * b_hi + a_hi * b_lo + a_lo * b_hi: three v_mfma_f32_16x16x32_bf16 per 16x16 tile and step, 3 * TC per
-//     MFMA group; taps unrolled, fragment reads two groups ahead, DMA pieces between MFMA groups.
+//   * a * b = a_hi * b_hi + a_hi * b_lo + a_lo * b_hi: three v_mfma_f32_16x16x32_bf16 per 16x16 tile and step; taps unrolled;
+//   * PING-PONG PHASES: the two waves that share a SIMD (wave w and w + 4: the cout halves wc = 0 / 1) run half a step out of
+//     phase.  A step is a READ phase (all 16 fragment reads of the step + the step's DMA issue) and an MFMA phase (48 MFMAs,
+//     nothing else) with a block barrier after each; group 1 starts one phase late, so while one wave of a SIMD streams MFMAs
+//     the other fetches.  Each group DMAs the weight rows of ITS cout half (nobody else reads them), which keeps the ring's
+//     two-step latency budget in both groups.  (The earlier single-phase version -- reads two MFMA groups ahead, DMA pieces
+//     between MFMA groups, one barrier per step -- was 1-8 % slower on every layer and was removed; it is in the history.)
 //
 // Against the flat 128-pixel tile this cuts the L2 -> LDS activation traffic of a 3x3 layer from nine fetches of every
 // input line to 1.27 (the halo), the round-1 limiter of the bf16x3 kernel ("both operands' L2 -> LDS
@@ -23,9 +28,7 @@ namespace cer {
 constexpr unsigned long long B3_PATCH_F_TABLE = 0xaaa00a00ull;
 __device__ __forceinline__ int b3_patch_f(int wx) { return (int)((B3_PATCH_F_TABLE >> (2 * wx)) & 3ull); }
 
-// PP = ping-pong phases (see conv_b3_win_kernel below): the two waves of a SIMD run half a step apart, one reads while the
-// other streams MFMAs.
-template <int BN, int WP, int WC, bool PP>
+template <int BN, int WP, int WC>
 __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs p) {
     constexpr int NW = WP * WC, NT = NW * 64;
     constexpr int PH = 16, PWD = 16, WW = 18, WROWS = 18 * 18;
@@ -38,7 +41,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
     constexpr int WQ = WPIECES / NW;                              // weight pieces per wave and step
     constexpr int TP = PH / WP, TC = BN / (16 * WC);
     static_assert(PH % WP == 0 && XPW <= 9 && TP >= 2, "geometry");
-    static_assert(!PP || (WP == 4 && WC == 2 && (BN / 16) % 4 == 0), "ping-pong: waves w and w + 4 share a SIMD and split the couts");
+    static_assert(WP == 4 && WC == 2 && (BN / 16) % 4 == 0, "ping-pong: waves w and w + 4 share a SIMD and split the couts");
     constexpr int WOFF = 2 * XBYTES, SINK = WOFF + 3 * WSLICE;    // LDS map: two windows | weight ring | 1 KiB sink
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_b3p[];
@@ -79,11 +82,11 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
     int w_plane[WQ], w_dst[WQ];
 #pragma unroll
     for (int i = 0; i < WQ; ++i) {
-        // PP: the group's own cout half, BN / 32 pieces per plane dealt to its four waves; else all pieces over all waves
-        const int j = PP ? (wave & 3) + 4 * i : wave + NW * i;
-        constexpr int PPL = PP ? BN / 32 : BN / 16;                 // pieces per plane in this wave's pool
+        // the group's own cout half, BN / 32 pieces per plane dealt to its four waves
+        const int j = (wave & 3) + 4 * i;
+        constexpr int PPL = BN / 32;                                // pieces per plane in this group's pool
         w_plane[i] = j / PPL;
-        const int pc = (PP ? (wave >> 2) * PPL : 0) + j % PPL;     // piece (16 cout rows) within the plane
+        const int pc = (wave >> 2) * PPL + j % PPL;                 // piece (16 cout rows) within the plane
         const int row = pc * 16 + prow;
         w_dst[i] = w_plane[i] * WPL + pc * 1024;
         w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ swz16((row >> 2) & 3)) << 3)) * 2) : OOB;
@@ -136,11 +139,9 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
     for (int i = 0; i < XPW; ++i) issue_x(i, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
-    if constexpr (PP) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WQ) : "memory");   // the window and slice 0 (slice 1 may still be in flight)
-        __builtin_amdgcn_s_barrier();
-        if (wc == 1) __builtin_amdgcn_s_barrier();                  // group 1 runs one phase behind group 0
-    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WQ) : "memory");   // the window and slice 0 (slice 1 may still be in flight)
+    __builtin_amdgcn_s_barrier();
+    if (wc == 1) __builtin_amdgcn_s_barrier();                  // group 1 runs one phase behind group 0
 
     // One step = one filter tap of one 32-channel chunk; per wave and step WQ weight pieces (slice of step s + 2) and, during
     // taps 0 .. XPW-1, the two planes of one window piece of the next chunk.  At the top of step s everything issued before
@@ -157,7 +158,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
             // drop the kernel stub)
             auto lda = [&](int a, int pl) { return *reinterpret_cast<const u32x4 *>(Wr + pl * WPL + arow + a * 16 * 64); };
             auto ldb = [&](int b, int pl) { return *reinterpret_cast<const u32x4 *>(Xb + pl * XPL + bcol[kw] + b * WP * WW * 64); };
-            if constexpr (PP) {
+            {
                 // ---- READ phase: every fragment of the step, then the step's DMA (slice of step + 2, a window piece) ----
                 u32x4 ah[TC], al[TC], bh[TP], bl[TP];
 #pragma unroll
@@ -193,47 +194,10 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-            } else {
-            constexpr int ptap = (tap + 8) % 9;
-            constexpr int pcnt = WQ + (ptap < XPW ? 2 : 0);
-            if (cc == 0 && tap == 0) {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");  // prologue: all but slice 1
-            } else {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            u32x4 ah[TC], al[TC], bh[TP], bl[TP];
-#pragma unroll
-            for (int a = 0; a < TC; ++a) { ah[a] = lda(a, 0); al[a] = lda(a, 1); }
-            bh[0] = ldb(0, 0); bl[0] = ldb(0, 1);
-            bh[1] = ldb(1, 0); bl[1] = ldb(1, 1);
-            static_for<TP>([&](auto G) {
-                constexpr int g = decltype(G)::v;
-                if constexpr (g + 2 < TP) { bh[g + 2] = ldb(g + 2, 0); bl[g + 2] = ldb(g + 2, 1); }
-                if constexpr (g == 0) issue_w(ncc, ntap, nring);
-                if constexpr (g == 1 && tap < XPW) issue_x(tap, cc + 1);
-#pragma unroll
-                for (int a = 0; a < TC; ++a) {
-                    acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
-                    acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bl[g]), acc[a][g], 0, 0, 0);
-                    acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
-                }
-            });
-            // issue order: the 3 * TC MFMAs of group g, then the reads for group g+2 and the group's DMA pieces
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TC + 4, 0);
-            static_for<TP>([&](auto G) {
-                constexpr int g = decltype(G)::v;
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * TC, 0);
-                if constexpr (g + 2 < TP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                constexpr int npiece = (g == 0 ? WQ : 0) + ((g == 1 && tap < XPW) ? 2 : 0);
-                if constexpr (npiece > 0) __builtin_amdgcn_sched_group_barrier(0x010, npiece, 0);
-            });
             }
         });
     }
-    if constexpr (PP) {
-        if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
-    }
+    if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sink pieces of the last steps
 
     // ---- epilogue: accumulators -> LDS (fp32, swizzled granules) -> compact coalesced loop, one patch row per iteration ----
@@ -310,14 +274,8 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
 // Taps that fall off the image (zero padding; the previous / next image row or frame in the flat array) are masked per lane:
 // such a lane reads the window's last row, which the DMA zero-fills.  Fragment rows start at any alignment; the swizzle
 // slot = chunk ^ ((row & 4) >> 1) is conflict free for every alignment (tools/check_swizzle.py).  Everything else -- weight
-// ring, counted vmcnt, unrolled taps, read pipeline, DMA placement -- is the patch kernel's.
-//
-// PP (ping-pong): the two waves that share a SIMD (wave w and w + 4: the cout halves wc = 0 / 1) run half a step out of phase.
-// A step is split into a READ phase (all 16 fragment reads of the step + the step's DMA issue) and an MFMA phase (48 MFMAs,
-// nothing else), with a block barrier after each; group 1 starts one phase late, so while one wave of a SIMD streams MFMAs the
-// other fetches -- the matrix pipe never waits for an LDS read.  Each group DMAs the weight rows of ITS cout half (nobody else
-// reads them), which keeps the two-step latency budget of the ring in both groups.
-template <int BN, int WP, int WC, bool PP>
+// ring, counted vmcnt, unrolled taps, ping-pong phases -- is the patch kernel's.
+template <int BN, int WP, int WC>
 __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p, int NP) {
     constexpr int NW = WP * WC, NT = NW * 64, BM = 256;
     constexpr int NPMAX = 27;                                     // window pieces (16 rows) per plane the LDS can hold twice
@@ -327,7 +285,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
     constexpr int WQ = WPIECES / NW;
     constexpr int TP = BM / (16 * WP), TC = BN / (16 * WC);
     static_assert(XPW <= 9 && TP >= 2, "geometry");
-    static_assert(!PP || (WP == 4 && WC == 2 && (BN / 16) % 4 == 0), "ping-pong: waves w and w + 4 share a SIMD and split the couts");
+    static_assert(WP == 4 && WC == 2 && (BN / 16) % 4 == 0, "ping-pong: waves w and w + 4 share a SIMD and split the couts");
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_b3p[];
     unsigned char *smem = reinterpret_cast<unsigned char *>(smem_b3p);
@@ -368,11 +326,11 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
     int w_plane[WQ], w_dst[WQ];
 #pragma unroll
     for (int i = 0; i < WQ; ++i) {
-        // PP: the group's own cout half, BN / 32 pieces per plane dealt to its four waves; else all pieces over all waves
-        const int j = PP ? (wave & 3) + 4 * i : wave + NW * i;
-        constexpr int PPL = PP ? BN / 32 : BN / 16;                 // pieces per plane in this wave's pool
+        // the group's own cout half, BN / 32 pieces per plane dealt to its four waves
+        const int j = (wave & 3) + 4 * i;
+        constexpr int PPL = BN / 32;                                // pieces per plane in this group's pool
         w_plane[i] = j / PPL;
-        const int pc = (PP ? (wave >> 2) * PPL : 0) + j % PPL;     // piece (16 cout rows) within the plane
+        const int pc = (wave >> 2) * PPL + j % PPL;                 // piece (16 cout rows) within the plane
         const int row = pc * 16 + prow;
         w_dst[i] = w_plane[i] * WPL + pc * 1024;
         w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ swz16((row >> 2) & 3)) << 3)) * 2) : OOB;
@@ -437,11 +395,9 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
     for (int i = 0; i < XPW; ++i) issue_x(i, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
-    if constexpr (PP) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WQ) : "memory");   // the window and slice 0 (slice 1 may still be in flight)
-        __builtin_amdgcn_s_barrier();
-        if (wc == 1) __builtin_amdgcn_s_barrier();                  // group 1 runs one phase behind group 0
-    }
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WQ) : "memory");   // the window and slice 0 (slice 1 may still be in flight)
+    __builtin_amdgcn_s_barrier();
+    if (wc == 1) __builtin_amdgcn_s_barrier();                  // group 1 runs one phase behind group 0
 
     for (int cc = 0; cc < cin_steps; ++cc) {
         const int xcur = (cc & 1) * XBYTES;
@@ -460,7 +416,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
                 baddr[b] = row * 64 + ((kg ^ ((row & 4) >> 1)) << 4);
             }
             auto ldb = [&](int b, int pl) { return *reinterpret_cast<const u32x4 *>(Xb + pl * XPL + baddr[b]); };
-            if constexpr (PP) {
+            {
                 // ---- READ phase: every fragment of the step, then the step's DMA (slice of step + 2, a window piece) ----
                 u32x4 ah[TC], al[TC], bh[TP], bl[TP];
 #pragma unroll
@@ -496,46 +452,10 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
-            } else {
-            constexpr int ptap = (tap + 8) % 9;
-            constexpr int pcnt = WQ + (ptap < XPW ? 2 : 0);
-            if (cc == 0 && tap == 0) {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");
-            } else {
-                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
-            }
-            __builtin_amdgcn_s_barrier();
-            u32x4 ah[TC], al[TC], bh[TP], bl[TP];
-#pragma unroll
-            for (int a = 0; a < TC; ++a) { ah[a] = lda(a, 0); al[a] = lda(a, 1); }
-            bh[0] = ldb(0, 0); bl[0] = ldb(0, 1);
-            bh[1] = ldb(1, 0); bl[1] = ldb(1, 1);
-            static_for<TP>([&](auto G) {
-                constexpr int g = decltype(G)::v;
-                if constexpr (g + 2 < TP) { bh[g + 2] = ldb(g + 2, 0); bl[g + 2] = ldb(g + 2, 1); }
-                if constexpr (g == 0) issue_w(ncc, ntap, nring);
-                if constexpr (g == 1 && tap < XPW) issue_x(tap, cc + 1);
-#pragma unroll
-                for (int a = 0; a < TC; ++a) {
-                    acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
-                    acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bl[g]), acc[a][g], 0, 0, 0);
-                    acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
-                }
-            });
-            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TC + 4, 0);
-            static_for<TP>([&](auto G) {
-                constexpr int g = decltype(G)::v;
-                __builtin_amdgcn_sched_group_barrier(0x008, 3 * TC, 0);
-                if constexpr (g + 2 < TP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                constexpr int npiece = (g == 0 ? WQ : 0) + ((g == 1 && tap < XPW) ? 2 : 0);
-                if constexpr (npiece > 0) __builtin_amdgcn_sched_group_barrier(0x010, npiece, 0);
-            });
             }
         });
     }
-    if constexpr (PP) {
-        if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
-    }
+    if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: accumulators -> LDS (fp32, swizzled granules) -> compact coalesced loop over consecutive output rows ----
@@ -617,22 +537,22 @@ static int b3_win_pieces(const ConvArgs &a) {
     return np <= 27 ? np : 0;                           // 4 * 27 KiB + the 48 KiB weight ring + sink <= 160 KiB: W <= 86
 }
 
-template <int BN, int WP, int WC, bool PP>
+template <int BN, int WP, int WC>
 static int launch_b3_win(const ConvArgs &a, hipStream_t st) {
     const int np = b3_win_pieces(a);
     size_t lds = (size_t)4 * np * 1024 + 3 * (size_t)2 * BN * 64 + 1024;
     if (lds < (size_t)256 * BN * 4) lds = (size_t)256 * BN * 4;   // the epilogue's accumulator tile
-    auto k = conv_b3_win_kernel<BN, WP, WC, PP>;
+    auto k = conv_b3_win_kernel<BN, WP, WC>;
     if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, 1), dim3(WP * WC * 64), lds, st, a, np);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }
 
-template <int BN, int WP, int WC, bool PP>
+template <int BN, int WP, int WC>
 static int launch_b3_patch(const ConvArgs &a, hipStream_t st) {
     const size_t lds = (size_t)2 * 2 * 21 * 1024 + 3 * (size_t)2 * BN * 64 + 1024;
-    auto k = conv_b3_patch_kernel<BN, WP, WC, PP>;
+    auto k = conv_b3_patch_kernel<BN, WP, WC>;
     if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, 1), dim3(WP * WC * 64), lds, st, a);
     CER_HIP_CHECK(hipGetLastError());
@@ -654,25 +574,18 @@ bool conv_b3_win_ok(const ConvArgs &a) {
 }
 
 int conv_b3_patch_launch(int tile, const ConvArgs &a, hipStream_t st) {
-    if (tile >= 53 && tile <= 56) {
+    if (tile == 55 || tile == 56) {
         if (!conv_b3_win_ok(a))
             return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3, window kernel): needs a 3x3 / stride 1 / pad 1 conv with W <= 86, "
                                                        "Cin % 32 == 0, no split-K");
-        switch (tile) {
-            case 53: return launch_b3_win<64, 4, 2, false>(a, st);
-            case 54: return launch_b3_win<128, 4, 2, false>(a, st);
-            case 55: return launch_b3_win<64, 4, 2, true>(a, st);     // ping-pong variants
-            default: return launch_b3_win<128, 4, 2, true>(a, st);
-        }
+        return tile == 55 ? launch_b3_win<64, 4, 2>(a, st) : launch_b3_win<128, 4, 2>(a, st);
     }
     if (!conv_b3_patch_ok(a))
         return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3, patch kernel): needs a 3x3 / stride 1 / pad 1 conv on images whose "
                                                    "height and width are multiples of 16, Cin % 32 == 0, no split-K");
     switch (tile) {
-        case 51: return launch_b3_patch<64, 4, 2, false>(a, st);
-        case 52: return launch_b3_patch<128, 4, 2, false>(a, st);
-        case 57: return launch_b3_patch<64, 4, 2, true>(a, st);      // ping-pong variants
-        case 58: return launch_b3_patch<128, 4, 2, true>(a, st);
+        case 57: return launch_b3_patch<64, 4, 2>(a, st);
+        case 58: return launch_b3_patch<128, 4, 2>(a, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3, patch kernel): unknown tile id");
     }
 }

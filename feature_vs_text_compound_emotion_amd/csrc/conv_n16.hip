@@ -359,11 +359,11 @@ static int launch_n16(const ConvArgs &a, hipStream_t st) {
     return CER_OK;
 }
 
-// tile ids (desc.tile): 0 = auto; flat kernels: 61 = 256x256 (8 waves), 62 = 256x128 (8 waves), 63 = 256x64 (4 waves),
-// 64 = 128x128, 65 = 128x64, 66 = 64x64, 67 = 64x128 (4 waves each), K step 64; 81-84 / 91, 94 = A/B variants of the DMA
-// placement; patch kernels (conv_n16_patch.hip, 3x3 / stride 1 / pad 1 on images with H, W % 16 == 0): 71 = 16x16 pixels x
-// 64 couts (Cin == 64), 72 = 16x16 pixels x 128 couts; 1-D window kernels (same file, 3x3 / stride 1 / pad 1 at ANY image size
-// with W <= 86: the window of 256 consecutive output pixels resident in LDS): 73 = 64 couts, 74 = 128 couts.
+// tile ids (desc.tile): 0 = auto; flat kernels (K step 64): 63 = 256x64, 64 = 128x128, 65 = 128x64, 66 = 64x64, 67 = 64x128
+// (4 waves each), 91 = 256x256 (8 waves) and 94 = 128x128 with the step's DMA pieces spread over the first half of the MFMA
+// groups; window-resident kernels (conv_n16_patch.hip, 3x3 / stride 1 / pad 1): patches of 16x16 pixels (H, W % 16 == 0):
+// 71 = 64 couts (Cin == 64, 4 waves, two blocks per CU), 72 = 128 couts, 78 = 128 couts with ping-pong phases; 1-D windows of
+// 256 consecutive pixels (any image size with W <= 86): 73 = 64 couts, 76 = 128 couts with ping-pong phases.
 static bool patch_geometry(const cer_conv_desc *d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil_h == 1 && d->dil_w == 1 && d->pad_t == 1 && d->pad_l == 1 &&
            d->Ho == d->H && d->Wo == d->W && (d->H & 15) == 0 && (d->W & 15) == 0 && (d->Cin & 63) == 0 && d->split_k <= 1;
@@ -395,17 +395,16 @@ int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
     }
     bk = 64;
     switch (tile) {
-        case 61: case 81: case 91: bm = 256; bn = 256; break;
-        case 62: case 82: bm = 256; bn = 128; break;
-        case 63: case 83: bm = 256; bn = 64; break;
-        case 64: case 84: case 94: bm = 128; bn = 128; break;
+        case 91: bm = 256; bn = 256; break;
+        case 63: bm = 256; bn = 64; break;
+        case 64: case 94: bm = 128; bn = 128; break;
         case 65: bm = 128; bn = 64; break;
         case 66: bm = 64; bn = 64; break;
         case 67: bm = 64; bn = 128; break;
         case 71: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels
         case 72: case 78: bm = 256; bn = 128; break;   // (78: ping-pong phases)
-        case 73: case 75: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels
-        case 74: case 76: bm = 256; bn = 128; break;   // (75 / 76: ping-pong phases)
+        case 73: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels
+        case 76: bm = 256; bn = 128; break;   // (ping-pong phases)
         default: return 0;
     }
     return tile;
@@ -413,20 +412,14 @@ int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
 
 int conv_n16_launch(int tile, const ConvArgs &a, hipStream_t st) {
     switch (tile) {
-        case 61: return launch_n16<256, 256, 2, 4>(a, st);
-        case 62: return launch_n16<256, 128, 4, 2>(a, st);
         case 63: return launch_n16<256, 64, 4, 1>(a, st);
         case 64: return launch_n16<128, 128, 2, 2>(a, st);
         case 65: return launch_n16<128, 64, 2, 2>(a, st);
         case 66: return launch_n16<64, 64, 2, 2>(a, st);
         case 67: return launch_n16<64, 128, 1, 4>(a, st);
-        case 71: case 72: case 73: case 74: case 75: case 76: case 78: return conv_n16_patch_launch(tile, a, st);
-        case 81: return launch_n16<256, 256, 2, 4, 0>(a, st);
-        case 82: return launch_n16<256, 128, 4, 2, 0>(a, st);
-        case 83: return launch_n16<256, 64, 4, 1, 0>(a, st);
+        case 71: case 72: case 73: case 76: case 78: return conv_n16_patch_launch(tile, a, st);
         case 91: return launch_n16<256, 256, 2, 4, 2>(a, st);
         case 94: return launch_n16<128, 128, 2, 2, 2>(a, st);
-        case 84: return launch_n16<128, 128, 2, 2, 0>(a, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (narrow): unknown tile id");
     }
 }

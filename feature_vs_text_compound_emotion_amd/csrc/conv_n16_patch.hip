@@ -646,16 +646,11 @@ bool conv_n16_patch_ok(const ConvArgs &a, int tile) {
 }
 
 int conv_n16_patch_launch(int tile, const ConvArgs &a, hipStream_t st) {
-    if (tile >= 73 && tile <= 76) {
+    if (tile == 73 || tile == 76) {
         if (!conv_n16_win_ok(a))
             return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow, window kernel): needs a 3x3 / stride 1 / pad 1 conv with W <= 86, "
                                                        "Cin % 64 == 0, no split-K");
-        switch (tile) {
-            case 73: return launch_win<64, 4, 2, false>(a, st);
-            case 74: return launch_win<128, 4, 2, false>(a, st);
-            case 75: return launch_win<64, 4, 2, true>(a, st);      // ping-pong variants
-            default: return launch_win<128, 4, 2, true>(a, st);
-        }
+        return tile == 73 ? launch_win<64, 4, 2, false>(a, st) : launch_win<128, 4, 2, true>(a, st);   // 76: ping-pong phases
     }
     if (!conv_n16_patch_ok(a, tile))
         return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow, patch kernel): needs a 3x3 / stride 1 / pad 1 conv on images whose "
