@@ -416,7 +416,8 @@ def compact(res):
     out = {"value": res["value"], "unit": res["unit"], "ms_per_step": res["ms_per_step"], "steps": res["steps"],
            "warmup": res["warmup"], "dtype": res["dtype"], "config": res["config"],
            "roofline": {k: r[k] for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "peak_note", "avg_launch_ms",
-                                          "launches_per_step", "algorithmic_bytes_per_launch") if k in r}}
+                                          "launches_per_step", "algorithmic_bytes_per_launch", "traffic",
+                                          "traffic_per_step_all_convs") if k in r}}
     if "encoder_span" in r:
         out["roofline"]["encoder_span"] = {k: r["encoder_span"][k] for k in ("achieved", "frac", "ms_per_step_in_kernel")}
     if "all_kernels" in r:
