@@ -220,7 +220,8 @@ class Workload:
                 for part in (bb.input_layer, bb.body, bb.output_layer):
                     for p in part.parameters():
                         p.requires_grad = True
-        self.ddp = ClipDataParallel(self.model, world_size=world)
+        # released encoder units (28-43 M parameters): exchange 25 MB slices of the bucket under the backward of the units below
+        self.ddp = ClipDataParallel(self.model, world_size=world, overlap=cfg["release"] > 0)
         # the reference's torch.optim.SGD(momentum .9, nesterov, wd 1e-4, lr 1e-3 -- F8) as one fused launch over flat buffers
         self.opt = FlatNesterovSGD(self.ddp, lr=1e-3, momentum=0.9, dampening=0.0, weight_decay=1e-4, nesterov=True)
         x, labels = synth.make_clip_batch(mods, cfg["batch"], length, hw=hw, seed=1234 + rank, n_cls=n_cls)

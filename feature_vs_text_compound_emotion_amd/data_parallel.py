@@ -41,7 +41,12 @@ def init_process_group_from_env(backend=None):
 class ClipDataParallel:
     """Gradient bucket + collectives for a model whose trainable part is small."""
 
-    def __init__(self, model, world_size=None, broadcast=True):
+    def __init__(self, model, world_size=None, broadcast=True, overlap=False, bucket_mb=25.0):
+        """``overlap``: cut the flat bucket into slices of ``bucket_mb`` (in parameter order) and start the all-reduce of a
+        slice from an autograd hook as soon as the last gradient of the slice has been accumulated -- backward produces
+        the gradients from the top of the model down, so with released encoder units (28-43 M parameters, 112-172 MB) the
+        exchange of the tail's and the upper units' gradients runs under the backward of the units below.  Needs ONE
+        ``backward()`` per ``zero_grad()`` (the reference's training loop); off by default."""
         self.model = model
         self.world = world_size if world_size is not None else (dist.get_world_size() if dist.is_initialized() else 1)
         self.params = [p for p in model.parameters() if p.requires_grad]
@@ -60,6 +65,41 @@ class ClipDataParallel:
         # starts dropout_seed at 0 -- fold the rank in (2^20 steps apart)
         if self.world > 1 and dist.is_initialized() and hasattr(model, "dropout_seed"):
             model.dropout_seed += dist.get_rank() << 20
+        self.overlap = bool(overlap) and self.world > 1 and dist.is_initialized()
+        self.buckets, self._works = [], []
+        if self.overlap:
+            self._build_buckets(bucket_mb)
+
+    # ------------------------------------------------------------------ bucketed, overlapped exchange
+    def _build_buckets(self, bucket_mb):
+        cap = max(1, int(bucket_mb * (1 << 20)) // 4)
+        start = off = 0
+        count = 0
+        index_of = []
+        for p in self.params:
+            if count and off + p.numel() - start > cap:
+                self.buckets.append([start, off, count])
+                start, count = off, 0
+            index_of.append(len(self.buckets))
+            off += p.numel()
+            count += 1
+        self.buckets.append([start, off, count])
+        self._pending = [b[2] for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        for p, b in zip(self.params, index_of):
+            p.register_post_accumulate_grad_hook(self._make_hook(b))
+
+    def _make_hook(self, b):
+        def hook(_param):
+            self._pending[b] -= 1
+            if self._pending[b] == 0 and not self._launched[b]:
+                self._launch(b)
+        return hook
+
+    def _launch(self, b):
+        s, e, _ = self.buckets[b]
+        self._launched[b] = True
+        self._works.append(dist.all_reduce(self.flat[s:e], op=dist.ReduceOp.SUM, async_op=True))
 
     def broadcast_state(self, src=0):
         """Replicate rank ``src``'s parameters and buffers (one flat message each).  The copies go through the tensors
@@ -102,6 +142,10 @@ class ClipDataParallel:
     def zero_grad(self):
         """Keeps the views alive (``optimizer.zero_grad(set_to_none=True)`` would drop them)."""
         self.flat.zero_()
+        if self.overlap:
+            self._pending = [b[2] for b in self.buckets]
+            self._launched = [False] * len(self.buckets)
+            self._works = []
         off = 0
         for p in self.params:
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
@@ -111,7 +155,15 @@ class ClipDataParallel:
     def all_reduce_gradients(self):
         """Mean of the gradients over ranks, in place in the bucket."""
         if self.world > 1:
-            dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
+            if self.overlap:
+                for b in range(len(self.buckets)):   # slices whose parameters got no gradient this step (still zeros)
+                    if not self._launched[b]:
+                        self._launch(b)
+                for w in self._works:
+                    w.wait()
+                self._works = []
+            else:
+                dist.all_reduce(self.flat, op=dist.ReduceOp.SUM)
             self.flat.mul_(1.0 / self.world)
 
     def flatten_parameters(self):

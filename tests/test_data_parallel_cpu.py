@@ -60,3 +60,55 @@ def test_single_process_bucket_views_and_zero_grad():
     assert model.weight.grad.data_ptr() == ddp.flat.data_ptr()
     ddp.zero_grad()
     assert ddp.flat.abs().sum() == 0 and model.weight.grad.abs().sum() == 0
+
+
+def _worker_overlap(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from feature_vs_text_compound_emotion_amd.data_parallel import ClipDataParallel, init_process_group_from_env
+    import torch.distributed as dist
+    init_process_group_from_env(backend="gloo")
+    res = {}
+    for overlap in (False, True):
+        torch.manual_seed(5)
+        model = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.ReLU(), torch.nn.Linear(64, 64), torch.nn.ReLU(),
+                                    torch.nn.Linear(64, 32), torch.nn.Linear(32, 3), torch.nn.Linear(3, 3))
+        model[6].weight.requires_grad = False        # frozen in the middle of a slice
+        for p in model[4].parameters():              # a whole slice that never receives a gradient (used under no_grad below)
+            p.requires_grad = True
+        # 8 KiB slices: the 12 trainable tensors fall into several buckets; the last ones fill first during backward
+        ddp = ClipDataParallel(model, overlap=overlap, bucket_mb=8 / 1024)
+        if overlap:
+            assert len(ddp.buckets) >= 3 and ddp.buckets[0][0] == 0 and ddp.buckets[-1][1] == sum(p.numel() for p in ddp.params)
+            assert all(a[1] == b[0] for a, b in zip(ddp.buckets, ddp.buckets[1:]))
+        g = torch.Generator().manual_seed(11 + rank)
+        flats = []
+        for step in range(2):
+            ddp.zero_grad()
+            x = torch.randn(6, 40, generator=g)
+            h = model[3](model[2](model[1](model[0](x))))
+            with torch.no_grad():
+                skip = model[4](h)                       # model[4] is outside the graph: its slice gets no gradient
+            y = model[6](model[5](skip + 0 * h[:, :32]))
+            y.square().mean().backward()
+            ddp.all_reduce_gradients()
+            flats.append(ddp.flat.clone())
+        res[overlap] = flats
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucket_exchange_equals_the_single_all_reduce():
+    """ClipDataParallel(overlap=True): slices of the flat bucket are all-reduced from autograd hooks as their last gradient
+    arrives (reverse order of the parameters), slices without any gradient at all_reduce_gradients(); the result is the same
+    mean as ONE all-reduce of the whole bucket, and both ranks hold it."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_overlap, args=(world, port, out), nprocs=world, join=True)
+        for rank in (0, 1):
+            for a, b in zip(out[rank][False], out[rank][True]):
+                assert torch.allclose(a, b, rtol=0, atol=1e-7) and a.abs().sum() > 0
+        for a, b in zip(out[0][True], out[1][True]):
+            assert torch.equal(a, b)
