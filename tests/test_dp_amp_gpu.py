@@ -63,7 +63,9 @@ def _worker(rank, world, port, out):
     init_process_group_from_env(backend="gloo")
     torch.cuda.set_device(0)
     model = _model(seed=rank)          # different weights per rank: broadcast_state must make them rank 0's
-    ddp = ClipDataParallel(model)
+    # the overlapped exchange: 2 MB slices of the 20 MB bucket, all-reduced from autograd hooks during the backward
+    ddp = ClipDataParallel(model, overlap=True, bucket_mb=2.0)
+    assert len(ddp.buckets) >= 5
     opt = FlatNesterovSGD(ddp, lr=1e-3)
     x, labels = synth.make_clip_batch(MODS, B, L, hw=HW, seed=55)
     idx = ddp.shard(list(range(B)), rank)
