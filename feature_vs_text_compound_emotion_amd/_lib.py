@@ -63,6 +63,7 @@ _SIGNATURES = {
     "cer_conv2d_wgrad": (c_int, [_P, _P, _P] + [c_int] * 12 + [_P]),
     "cer_conv2d_wgrad_b3_workspace_bytes": (c_size_t, [c_int] * 7),
     "cer_conv2d_wgrad_b3": (c_int, [_P, _P, _P] + [c_int] * 12 + [_P, c_size_t, _P]),
+    "cer_conv2d_wgrad_b3s": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 12 + [_P, c_size_t, _P]),
     "cer_prelu_fwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
     "cer_prelu_bwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, _P]),
     "cer_col_sum_workspace_bytes": (c_size_t, [c_int, c_int]),

@@ -30,7 +30,8 @@ __device__ __forceinline__ bf16x8 as_bf16(const s16x8 v) { return __builtin_bit_
 typedef __attribute__((address_space(3))) s16x4 *lds_s16x4_ptr;
 
 struct Wgrad2dArgs {
-    const float *dz, *x;
+    const float *dz, *x;                        // fp32 operands (split into hi / lo bf16 by the loader) ...
+    const uint16_t *dz_hi, *dz_lo, *x_hi, *x_lo;   // ... or operands that are split tensors already (SPLIT_IN)
     float *out;          // dw, or the partial slabs [splits][Cout * Cin * KH * KW]
     int R, Cout, Cin, KHW, KW, H, W, Ho, Wo, stride, pad_t, pad_l;
     int rows_per_split;  // multiple of 32
@@ -41,7 +42,10 @@ __device__ __forceinline__ int wg_off(int row, int ch) { return 256 * row + 16 *
 
 // TS = output tile edge: 128 (wave = 64 x 64 = 4 x 4 MFMA tiles) or 64 (wave = 32 x 32: the 64-channel layers and the stem
 // without the 2-4x of zero columns a 128-wide tile would multiply)
-template <int TS>
+// SPLIT_IN: dZ and X arrive as split tensors (hi / lo bf16 planes, what the released units' forward and data-gradient convs
+// consume anyway): the loader copies 8 bytes per plane instead of converting -- the conversion of fp32 operands, redone by
+// every (tile, tap) block, was half of the kernel's issue slots (PMC: "active" 51 % at MFMA busy 23 %).
+template <int TS, bool SPLIT_IN>
 __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) {
     constexpr int KS = 32, PLANE = KS * 256, STAGE = 4 * PLANE;       // planes per stage: dZ hi, dZ lo, X hi, X lo
     constexpr int NTW = TS / 32;                                      // 16-wide MFMA tiles per wave and side
@@ -68,7 +72,7 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
     const int col4 = (tid % TPR) * 4, lrow = tid / TPR;               // rows lrow + (256 / TPR) i
     constexpr int RSTEP = 256 / TPR;
     const int hw = p.Ho * p.Wo;
-    float4 ra[LPT], rb[LPT];
+    float4 ra[LPT], rb[LPT];            // fp32 operands: 4 floats; split operands: .x/.y = the hi plane's 8 bytes, .z/.w = lo
     // (n, ho, wo) of this thread's rows, advanced by the 32 rows of a step without divisions (the index arithmetic of the
     // loader was half of the wave's issue slots: PMC "active" 51 % at MFMA busy 23 %)
     int pn[LPT], pho[LPT], pwo[LPT];
@@ -89,10 +93,22 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
             if (r < r_end) {
                 // (channel counts are multiples of 4; columns past Cout / Cin stay zero: 64-channel layers and the 3 -> 4
                 // channel stem use part of the tile)
-                if (co0 + col4 < p.Cout) a = *reinterpret_cast<const float4 *>(p.dz + (size_t)r * p.Cout + co0 + col4);
                 const int hi = pho[i] * p.stride - p.pad_t + kh, wi_ = pwo[i] * p.stride - p.pad_l + kw;
-                if (ci0 + col4 < p.Cin && (unsigned)hi < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.W)
-                    b = *reinterpret_cast<const float4 *>(p.x + (((size_t)pn[i] * p.H + hi) * p.W + wi_) * p.Cin + ci0 + col4);
+                const bool xin = ci0 + col4 < p.Cin && (unsigned)hi < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.W;
+                const size_t ao = (size_t)r * p.Cout + co0 + col4, bo = (((size_t)pn[i] * p.H + hi) * p.W + wi_) * p.Cin + ci0 + col4;
+                if constexpr (SPLIT_IN) {
+                    if (co0 + col4 < p.Cout) {
+                        const float2 h = *reinterpret_cast<const float2 *>(p.dz_hi + ao), l = *reinterpret_cast<const float2 *>(p.dz_lo + ao);
+                        a = make_float4(h.x, h.y, l.x, l.y);
+                    }
+                    if (xin) {
+                        const float2 h = *reinterpret_cast<const float2 *>(p.x_hi + bo), l = *reinterpret_cast<const float2 *>(p.x_lo + bo);
+                        b = make_float4(h.x, h.y, l.x, l.y);
+                    }
+                } else {
+                    if (co0 + col4 < p.Cout) a = *reinterpret_cast<const float4 *>(p.dz + ao);
+                    if (xin) b = *reinterpret_cast<const float4 *>(p.x + bo);
+                }
             }
             ra[i] = a;
             rb[i] = b;
@@ -114,14 +130,21 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
         for (int i = 0; i < LPT; ++i) {
             const int row = lrow + RSTEP * i;
             const int byte = wg_off(row, col4 >> 3) + 8 * ((col4 >> 2) & 1);
-            const float va[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w}, vb[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
-            ushort4 h, l;
-            split_bf16(va[0], h.x, l.x); split_bf16(va[1], h.y, l.y); split_bf16(va[2], h.z, l.z); split_bf16(va[3], h.w, l.w);
-            *reinterpret_cast<ushort4 *>(base + byte) = h;
-            *reinterpret_cast<ushort4 *>(base + PLANE + byte) = l;
-            split_bf16(vb[0], h.x, l.x); split_bf16(vb[1], h.y, l.y); split_bf16(vb[2], h.z, l.z); split_bf16(vb[3], h.w, l.w);
-            *reinterpret_cast<ushort4 *>(base + 2 * PLANE + byte) = h;
-            *reinterpret_cast<ushort4 *>(base + 3 * PLANE + byte) = l;
+            if constexpr (SPLIT_IN) {
+                *reinterpret_cast<float2 *>(base + byte) = make_float2(ra[i].x, ra[i].y);
+                *reinterpret_cast<float2 *>(base + PLANE + byte) = make_float2(ra[i].z, ra[i].w);
+                *reinterpret_cast<float2 *>(base + 2 * PLANE + byte) = make_float2(rb[i].x, rb[i].y);
+                *reinterpret_cast<float2 *>(base + 3 * PLANE + byte) = make_float2(rb[i].z, rb[i].w);
+            } else {
+                const float va[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w}, vb[4] = {rb[i].x, rb[i].y, rb[i].z, rb[i].w};
+                ushort4 h, l;
+                split_bf16(va[0], h.x, l.x); split_bf16(va[1], h.y, l.y); split_bf16(va[2], h.z, l.z); split_bf16(va[3], h.w, l.w);
+                *reinterpret_cast<ushort4 *>(base + byte) = h;
+                *reinterpret_cast<ushort4 *>(base + PLANE + byte) = l;
+                split_bf16(vb[0], h.x, l.x); split_bf16(vb[1], h.y, l.y); split_bf16(vb[2], h.z, l.z); split_bf16(vb[3], h.w, l.w);
+                *reinterpret_cast<ushort4 *>(base + 2 * PLANE + byte) = h;
+                *reinterpret_cast<ushort4 *>(base + 3 * PLANE + byte) = l;
+            }
         }
     };
 
@@ -237,11 +260,12 @@ extern "C" size_t cer_conv2d_wgrad_b3_workspace_bytes(int N, int Ho, int Wo, int
     return splits > 1 ? (size_t)splits * Cout * Cin * KH * KW * sizeof(float) : 0;
 }
 
-extern "C" int cer_conv2d_wgrad_b3(const float *dz, const float *x, float *dw, int N, int H, int W, int Ho, int Wo, int Cout,
-                                   int Cin, int KH, int KW, int stride, int pad_t, int pad_l, void *workspace,
-                                   size_t workspace_bytes, void *stream) {
-    if (!dz || !x || !dw || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0 ||
-        stride <= 0 || pad_t < 0 || pad_l < 0 || (long long)N * Ho * Wo >= (1ll << 31) || KH * KW > 65535)
+static int wgrad_b3_run(const float *dz, const float *x, const uint16_t *dz_hi, const uint16_t *dz_lo, const uint16_t *x_hi,
+                        const uint16_t *x_lo, float *dw, int N, int H, int W, int Ho, int Wo, int Cout, int Cin, int KH, int KW,
+                        int stride, int pad_t, int pad_l, void *workspace, size_t workspace_bytes, void *stream) {
+    const bool split_in = dz_hi != nullptr;
+    if ((split_in ? (!dz_lo || !x_hi || !x_lo) : (!dz || !x)) || !dw || N <= 0 || H <= 0 || W <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 ||
+        Cin <= 0 || KH <= 0 || KW <= 0 || stride <= 0 || pad_t < 0 || pad_l < 0 || (long long)N * Ho * Wo >= (1ll << 31) || KH * KW > 65535)
         return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_wgrad_b3: bad argument");
     if ((Cout & 3) || (Cin & 3))
         return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d_wgrad_b3: Cout and Cin must be multiples of 4 (use cer_conv2d_wgrad)");
@@ -251,14 +275,36 @@ extern "C" int cer_conv2d_wgrad_b3(const float *dz, const float *x, float *dw, i
     const size_t n = (size_t)Cout * Cin * taps;
     if (splits > 1 && (!workspace || workspace_bytes < (size_t)splits * n * sizeof(float)))
         return cer_set_error(CER_ERR_WORKSPACE, "conv2d_wgrad_b3: workspace too small");
-    Wgrad2dArgs a{dz, x, splits > 1 ? (float *)workspace : dw, R, Cout, Cin, taps, KW, H, W, Ho, Wo, stride, pad_t, pad_l, 0, tiles, splits};
+    Wgrad2dArgs a{dz, x, dz_hi, dz_lo, x_hi, x_lo, splits > 1 ? (float *)workspace : dw, R, Cout, Cin, taps, KW, H, W, Ho, Wo,
+                  stride, pad_t, pad_l, 0, tiles, splits};
     a.rows_per_split = ((R + splits - 1) / splits + 31) / 32 * 32;
     const dim3 grid((unsigned)((splits + 7) / 8 * 8 * tiles * taps));
-    if (ts == 64) CER_LAUNCH(conv2d_wgrad_b3_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else CER_LAUNCH(conv2d_wgrad_b3_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
+    hipStream_t st = (hipStream_t)stream;
+    if (ts == 64) {
+        if (split_in) CER_LAUNCH((conv2d_wgrad_b3_kernel<64, true>), grid, dim3(256), 0, st, a);
+        else CER_LAUNCH((conv2d_wgrad_b3_kernel<64, false>), grid, dim3(256), 0, st, a);
+    } else {
+        if (split_in) CER_LAUNCH((conv2d_wgrad_b3_kernel<128, true>), grid, dim3(256), 0, st, a);
+        else CER_LAUNCH((conv2d_wgrad_b3_kernel<128, false>), grid, dim3(256), 0, st, a);
+    }
     if (splits > 1)
-        CER_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                   (const float4 *)workspace, (float4 *)dw, n / 4, splits);
+        CER_LAUNCH(wgrad_reduce_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, (const float4 *)workspace, (float4 *)dw,
+                   n / 4, splits);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
+}
+
+extern "C" int cer_conv2d_wgrad_b3(const float *dz, const float *x, float *dw, int N, int H, int W, int Ho, int Wo, int Cout,
+                                   int Cin, int KH, int KW, int stride, int pad_t, int pad_l, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+    return wgrad_b3_run(dz, x, nullptr, nullptr, nullptr, nullptr, dw, N, H, W, Ho, Wo, Cout, Cin, KH, KW, stride, pad_t, pad_l, workspace,
+                        workspace_bytes, stream);
+}
+
+extern "C" int cer_conv2d_wgrad_b3s(const uint16_t *dz_hi, const uint16_t *dz_lo, const uint16_t *x_hi, const uint16_t *x_lo,
+                                    float *dw, int N, int H, int W, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride,
+                                    int pad_t, int pad_l, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!dz_hi) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_wgrad_b3s: NULL operand");
+    return wgrad_b3_run(nullptr, nullptr, dz_hi, dz_lo, x_hi, x_lo, dw, N, H, W, Ho, Wo, Cout, Cin, KH, KW, stride, pad_t, pad_l, workspace,
+                        workspace_bytes, stream);
 }

@@ -462,7 +462,23 @@ def l2norm_rows(x):
 def conv2d_wgrad(dz, x, kh, kw, stride=1, pad=(0, 0), b3=False):
     """dW [Cout,Cin,KH,KW] (torch layout) from dz [N,Ho,Wo,Cout] and the conv input x [N,H,W,Cin] (both dense NHWC).
     ``b3``: the bf16x3 MFMA kernel with the pixel range split over blocks (Cout, Cin % 4 == 0; other shapes take the
-    fp32-MFMA kernel either way)."""
+    fp32-MFMA kernel either way).  ``dz`` / ``x`` may be ``Split`` tensors (then both are used split: no conversion in the
+    kernel's loader)."""
+    split_in = isinstance(dz, Split) or isinstance(x, Split)
+    if split_in:
+        dz = dz if isinstance(dz, Split) else split_bf16(dz)
+        x = x if isinstance(x, Split) else split_bf16(x)
+        n, ho, wo, cout = dz.hi.shape
+        _, h, w, cin = x.hi.shape
+        if cout % 4 or cin % 4:
+            raise ValueError("conv2d_wgrad on split tensors needs channel counts that are multiples of 4")
+        dw = torch.empty((cout, cin, kh, kw), device=dz.hi.device, dtype=torch.float32)
+        lib = _lib.load()
+        nbytes = lib.cer_conv2d_wgrad_b3_workspace_bytes(n, ho, wo, cout, cin, kh, kw)
+        ws = torch.empty((nbytes // 4,), device=dw.device, dtype=torch.float32) if nbytes else None
+        check(lib.cer_conv2d_wgrad_b3s(ptr(dz.hi), ptr(dz.lo), ptr(x.hi), ptr(x.lo), ptr(dw), n, h, w, ho, wo, cout, cin, kh, kw,
+                                       stride, pad[0], pad[1], ptr(ws), nbytes, current_stream()), "cer_conv2d_wgrad_b3s")
+        return dw
     _dev_f32(dz, "dz")
     _dev_f32(x, "x")
     n, ho, wo, cout = dz.shape

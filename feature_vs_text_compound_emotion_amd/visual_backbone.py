@@ -49,9 +49,9 @@ def _conv_prec(x, wp, kh, kw, stride, pad, prec):
     product, <= 2^-15 relative per product), narrow storage ("bf16" / "fp16": operands rounded once, one MFMA), or the exact
     fp32 kernels.  Used by the released units' forward and data-gradient convs (the reference runs them in the same
     arithmetic as the rest of the encoder: fp32, or fp16 under --amp autocast)."""
-    if prec == "bf16x3":
-        return ops.conv2d_b3(ops.split_bf16(x), ops.split_bf16(wp), kh, kw, stride=stride, pad=pad, out_f32=True,
-                             out_split=False)["y"]
+    if prec == "bf16x3":   # x may be a Split already (the released units keep their conv inputs split for the weight gradient)
+        xs = x if isinstance(x, ops.Split) else ops.split_bf16(x)
+        return ops.conv2d_b3(xs, ops.split_bf16(wp), kh, kw, stride=stride, pad=pad, out_f32=True, out_split=False)["y"]
     if prec in ("bf16", "fp16"):
         dt = torch.bfloat16 if prec == "bf16" else torch.float16
         return ops.conv2d_n16(ops.to_n16(x, dt), ops.to_n16(wp, dt), kh, kw, stride=stride, pad=pad, out_f32=True,
@@ -68,6 +68,8 @@ def _conv_dgrad(dy, w_oihw, stride, pad, in_hw, prec="fp32"):
     n, ho, wo, c = dy.shape
     hu, wu = in_hw[0] - kh + 1 + 2 * pad, in_hw[1] - kw + 1 + 2 * pad
     if stride > 1 or (hu, wu) != (ho, wo):
+        if isinstance(dy, ops.Split):
+            dy = dy.float()
         up = torch.zeros((n, hu, wu, c), device=dy.device, dtype=dy.dtype)
         up[:, :(ho - 1) * stride + 1:stride, :(wo - 1) * stride + 1:stride] = dy
         dy = up
@@ -87,9 +89,14 @@ class _ReleasedUnit(torch.autograd.Function):
         xb, sm1, si1 = ops.bn_rows_fwd(x.view(-1, cin), g1.detach(), b1.detach(), bn1.running_mean, bn1.running_var, True,
                                        bn1.eps, bn1.momentum)
         xb = xb.view(n, h, w, cin)
-        z1 = _conv_prec(xb, ops.pack_conv_weight(w1.detach().contiguous()), 3, 3, 1, (1, 1), prec)
+        b3 = prec == "bf16x3"
+        # bf16x3: the conv inputs are split once and kept split for the weight-gradient kernel (same bytes as fp32)
+        xb_k = ops.split_bf16(xb) if b3 else xb
+        z1 = _conv_prec(xb_k, ops.pack_conv_weight(w1.detach().contiguous()), 3, 3, 1, (1, 1), prec)
         t1 = ops.prelu_fwd(z1, a1.detach().contiguous())
-        z2 = _conv_prec(t1, ops.pack_conv_weight(w2.detach().contiguous()), 3, 3, s, (1, 1), prec)
+        t1_k = ops.split_bf16(t1) if b3 else t1
+        z2 = _conv_prec(t1_k, ops.pack_conv_weight(w2.detach().contiguous()), 3, 3, s, (1, 1), prec)
+        del xb, t1
         _, ho, wo, depth = z2.shape
         out, sm2, si2 = ops.bn_rows_fwd(z2.view(-1, depth), g2.detach(), b2.detach(), bn2.running_mean, bn2.running_var, True,
                                         bn2.eps, bn2.momentum)
@@ -103,8 +110,9 @@ class _ReleasedUnit(torch.autograd.Function):
             ops.add_inplace(out, sc.view(n, ho, wo, depth))
         else:
             ops.add_inplace(out, x[:, ::s, ::s].contiguous() if s > 1 else x)  # MaxPool2d(1, s) == subsample
-        ctx.save_for_backward(x, xb, z1, t1, z2, sm1, si1, sm2, si2, zs, sms, sis, g1.detach(), w1.detach(), a1.detach(),
-                              w2.detach(), g2.detach(), ws.detach() if ws is not None else None,
+        ctx.save_for_backward(x, xb_k.hi if b3 else xb_k, xb_k.lo if b3 else None, z1, t1_k.hi if b3 else t1_k,
+                              t1_k.lo if b3 else None, z2, sm1, si1, sm2, si2, zs, sms, sis, g1.detach(), w1.detach(),
+                              a1.detach(), w2.detach(), g2.detach(), ws.detach() if ws is not None else None,
                               gs.detach() if gs is not None else None)
         ctx.stride = s
         ctx.prec = prec
@@ -112,7 +120,7 @@ class _ReleasedUnit(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        x, xb, z1, t1, z2, sm1, si1, sm2, si2, zs, sms, sis, g1, w1, a1, w2, g2, ws, gs = ctx.saved_tensors
+        x, xb, xb_lo, z1, t1, t1_lo, z2, sm1, si1, sm2, si2, zs, sms, sis, g1, w1, a1, w2, g2, ws, gs = ctx.saved_tensors
         s, prec = ctx.stride, ctx.prec
         n, h, w, cin = x.shape
         _, ho, wo, depth = z2.shape
@@ -120,9 +128,15 @@ class _ReleasedUnit(torch.autograd.Function):
         dz2, dg2, db2 = ops.bn_rows_bwd(dout.view(-1, depth), z2.view(-1, depth), sm2, si2, g2)
         dz2 = dz2.view(n, ho, wo, depth)
         b3 = prec != "fp32"   # the weight gradients follow the convs onto the bf16x3 matrix-core kernel
+        split = xb_lo is not None   # bf16x3: operands stay split (one conversion per tensor, shared by wgrad and dgrad)
+        if split:
+            xb, t1 = ops.Split(xb, xb_lo), ops.Split(t1, t1_lo)
+            dz2 = ops.split_bf16(dz2)
         dw2 = ops.conv2d_wgrad(dz2, t1, 3, 3, stride=s, pad=(1, 1), b3=b3)
         dt1 = _conv_dgrad(dz2, w2, s, 1, (h, w), prec)
         dz1, da1 = ops.prelu_bwd(dt1, z1, a1.contiguous())
+        if split:
+            dz1 = ops.split_bf16(dz1)
         dw1 = ops.conv2d_wgrad(dz1, xb, 3, 3, stride=1, pad=(1, 1), b3=b3)
         need_dx = ctx.needs_input_grad[0]
         dxb = _conv_dgrad(dz1, w1, 1, 1, (h, w), prec)
@@ -132,6 +146,8 @@ class _ReleasedUnit(torch.autograd.Function):
         if ws is not None:
             dzs, dgs, dbs = ops.bn_rows_bwd(dout.view(-1, depth), zs.view(-1, depth), sms, sis, gs)
             dzs = dzs.view(n, ho, wo, depth)
+            if split and s == 1:
+                dzs = ops.split_bf16(dzs)
             dws = ops.conv2d_wgrad(dzs, x, 1, 1, stride=s, pad=(0, 0), b3=b3)
             if need_dx:
                 ops.add_inplace(dx, _conv_dgrad(dzs, ws, s, 0, (h, w), prec))

@@ -217,6 +217,11 @@ int cer_conv2d_wgrad(const float *dz, const float *x, float *dw, int N, int H, i
 size_t cer_conv2d_wgrad_b3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW);
 int cer_conv2d_wgrad_b3(const float *dz, const float *x, float *dw, int N, int H, int W, int Ho, int Wo, int Cout, int Cin,
                         int KH, int KW, int stride, int pad_t, int pad_l, void *workspace, size_t workspace_bytes, void *stream);
+/* The same on operands that are split tensors already (hi / lo bf16 planes, cer_split_bf16): the loader copies instead of
+ * converting -- twice as fast when the caller has the split tensors anyway (the released units' convs consume them). */
+int cer_conv2d_wgrad_b3s(const uint16_t *dz_hi, const uint16_t *dz_lo, const uint16_t *x_hi, const uint16_t *x_lo, float *dw,
+                         int N, int H, int W, int Ho, int Wo, int Cout, int Cin, int KH, int KW, int stride, int pad_t, int pad_l,
+                         void *workspace, size_t workspace_bytes, void *stream);
 
 /* Channels-last PReLU with per-channel slopes (arcface_model.py:54).  Backward: dx = x > 0 ? dy : alpha*dy, and
  * dalpha_terms = x > 0 ? 0 : x*dy, whose column sum (cer_col_sum) is the slope gradient. */

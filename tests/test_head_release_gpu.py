@@ -280,6 +280,9 @@ def test_conv2d_wgrad_b3_and_dgrad_in_the_encoder_precision(n, cin, cout, hw, k,
     bound = wa.grad * (2.0 ** -15 + npix * 2.0 ** -24) + 1e-6
     err = (dw.cpu().double() - w.grad).abs()
     assert (err <= bound).all(), (err / bound).max().item()
+    # operands that are split tensors already (what the released units keep): the same arithmetic, no conversion in the loader
+    dw_s = ops.conv2d_wgrad(ops.split_bf16(dz), ops.split_bf16(xd), k, k, stride=stride, pad=(k // 2, k // 2), b3=True)
+    assert torch.equal(dw_s, dw)
     ref_fp32 = ops.conv2d_wgrad(dz, xd, k, k, stride=stride, pad=(k // 2, k // 2))          # the fp32-MFMA kernel agrees
     assert (ref_fp32.cpu().double() - w.grad).abs().max().item() < 1e-3 * max(1.0, w.grad.abs().max().item())
     dx = _conv_dgrad(dz, w.detach().float().cuda(), stride, k // 2, (hw, hw), prec)
