@@ -164,3 +164,47 @@ def test_bn_apply_split_io():
     assert (o["split"].float().cpu() - o["y"].cpu()).abs().max().item() < 2e-4
     st = o["stats"].cpu().sum(0)
     assert (st[0] - ref.sum((0, 1, 2))).abs().max().item() < 1e-2
+
+
+@pytest.mark.parametrize("tile,hw", [(56, 14), (58, 16), (41, 9), (55, 10), (57, 16)])
+@pytest.mark.parametrize("kind", ["raw_f32", "b9_prelu_split", "bias_res_split"])
+def test_specialised_row_epilogues_on_every_kernel_family(kind, tile, hw):
+    """The straight-line row epilogues (conv_common.h: epi_mode / epi_row) are selected by the EXACT combination of outputs a
+    launch asks for; here each of the three bf16x3 combinations alone, on the window, patch and flat kernels, against float64:
+    raw conv result -> fp32 (+ statistics); border bias (folded input BatchNorm) + PReLU -> split; bias + same-geometry split
+    residual -> split."""
+    from feature_vs_text_compound_emotion_amd import ops
+    cin, cout = 64, (64 if tile in (55, 57) else 128)
+    n = 5
+    g = torch.Generator().manual_seed(tile * 10 + len(kind))
+    x = torch.randn(n, cin, hw, hw, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    xs = ops.split_bf16(x.permute(0, 2, 3, 1).contiguous().cuda())
+    mag = F.conv2d(x.double().abs(), wt.double().abs(), None, 1, 1)
+    tol = mag * (2.0 ** -15 + cin * 9 * 2.0 ** -24) + 2e-6
+    if kind == "raw_f32":
+        ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+        r = ops.conv2d_b3(xs, ops.split_bf16(ops.pack_conv_weight(wt.cuda())), 3, 3, pad=(1, 1), tile=tile, out_f32=True,
+                          out_split=False, want_stats=True)
+        got = r["y"].cpu().permute(0, 3, 1, 2).double()
+        st = r["stats"].cpu().double().sum(0)
+        assert (st[0] - ref.sum((0, 2, 3))).abs().max().item() < 1e-2 and (st[1] - (ref * ref).sum((0, 2, 3))).abs().max().item() < 1e-2
+    elif kind == "b9_prelu_split":
+        s1, t1 = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.5
+        alpha = torch.rand(cout, generator=g) * 0.3 + 0.1
+        z = F.conv2d((x * s1.view(1, -1, 1, 1) + t1.view(1, -1, 1, 1)).double(), wt.double(), None, 1, 1)
+        ref = torch.where(z >= 0, z, z * alpha.double().view(1, -1, 1, 1))
+        wp, b9 = ops.fold_bn_3x3_packed(ops.pack_conv_weight(wt.cuda()), s1.cuda(), t1.cuda(), "split")
+        r = ops.conv2d_b3(xs, wp, 3, 3, pad=(1, 1), alpha=alpha.cuda(), act1=ops.ACT_PRELU, bias9=b9, tile=tile)
+        got = r["split"].float().cpu().permute(0, 3, 1, 2).double()
+        tol = tol * 2.5 + 2.0 ** -15 * ref.abs()      # |s1| <= 1.5 scales the products; the split output rounds once more
+    else:
+        bias = torch.randn(cout, generator=g)
+        res = torch.randn(n, cout, hw, hw, generator=g)
+        ref = F.conv2d(x.double(), wt.double(), bias.double(), 1, 1) + res.double()
+        rs = ops.split_bf16(res.permute(0, 2, 3, 1).contiguous().cuda())
+        r = ops.conv2d_b3(xs, ops.split_bf16(ops.pack_conv_weight(wt.cuda())), 3, 3, pad=(1, 1), bias=bias.cuda(), residual=rs,
+                          tile=tile)
+        got = r["split"].float().cpu().permute(0, 3, 1, 2).double()
+        tol = tol + 2.0 ** -14 * (ref.abs() + res.double().abs())   # split residual in, split result out
+    assert ((got - ref).abs() <= tol).all(), ((got - ref).abs() / tol).max().item()

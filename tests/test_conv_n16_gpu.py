@@ -258,3 +258,44 @@ def test_bn_apply_narrow_io(dtype):
     v = z * s + t
     ref = torch.where(v >= 0, v, v * alpha) * mask + (r32 * rs + rt)
     assert (o["y"].cpu() - ref).abs().max().item() < 1e-5
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("tile,hw", [(76, 14), (78, 16), (72, 16), (91, 9), (73, 10), (71, 16)])
+@pytest.mark.parametrize("kind", ["raw_n16", "b9_prelu_n16", "bias_res_n16"])
+def test_specialised_row_epilogues_on_every_narrow_kernel_family(kind, tile, hw, dtype):
+    """The three narrow launch kinds of the encoder, each alone, on the window, patch and flat kernels: the narrow output must
+    be the float64 result of the same (already rounded) operands, rounded once -- up to the fp32 accumulation."""
+    from feature_vs_text_compound_emotion_amd import ops
+    cin, cout = 64, (64 if tile in (73, 71) else 128)
+    n = 5
+    g = torch.Generator().manual_seed(tile * 10 + len(kind))
+    x = torch.randn(n, cin, hw, hw, generator=g).to(dtype)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).to(dtype)
+    xd = x.permute(0, 2, 3, 1).contiguous().cuda()
+    ulp = 2.0 ** (-8 if dtype == torch.bfloat16 else -11)
+    if kind == "raw_n16":
+        ref = F.conv2d(x.double(), wt.double(), None, 1, 1)
+        wn = ops.to_n16(ops.pack_conv_weight(wt.float().cuda()), dtype)
+        r = ops.conv2d_n16(xd, wn, 3, 3, pad=(1, 1), tile=tile, want_stats=True)
+        st = r["stats"].cpu().double().sum(0)
+        assert (st[0] - ref.sum((0, 2, 3))).abs().max().item() < 1e-2
+    elif kind == "b9_prelu_n16":
+        s1, t1 = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.5
+        alpha = torch.rand(cout, generator=g) * 0.3 + 0.1
+        wp, b9 = ops.fold_input_bn_3x3(wt.float().cuda(), s1.cuda(), t1.cuda())
+        wn = ops.to_n16(wp, dtype)
+        w_eff = (wt.float() * s1.view(1, -1, 1, 1)).to(dtype).double()
+        shift_img = torch.ones(1, cin, hw, hw, dtype=torch.float64) * t1.double().view(1, -1, 1, 1)
+        z = F.conv2d(x.double(), w_eff, None, 1, 1) + F.conv2d(shift_img, wt.double(), None, 1, 1)
+        ref = torch.where(z >= 0, z, z * alpha.double().view(1, -1, 1, 1))
+        r = ops.conv2d_n16(xd, wn, 3, 3, pad=(1, 1), alpha=alpha.cuda(), act1=ops.ACT_PRELU, bias9=b9, tile=tile)
+    else:
+        bias = torch.randn(cout, generator=g)
+        res = torch.randn(n, cout, hw, hw, generator=g).to(dtype)
+        ref = F.conv2d(x.double(), wt.double(), bias.double(), 1, 1) + res.double()
+        wn = ops.to_n16(ops.pack_conv_weight(wt.float().cuda()), dtype)
+        r = ops.conv2d_n16(xd, wn, 3, 3, pad=(1, 1), bias=bias.cuda(), residual=res.permute(0, 2, 3, 1).contiguous().cuda(),
+                           tile=tile)
+    got = r["n16"].float().cpu().permute(0, 3, 1, 2).double()
+    assert ((got - ref).abs() <= ulp * ref.abs() + 3e-5).all(), ((got - ref).abs() - ulp * ref.abs()).max().item()
