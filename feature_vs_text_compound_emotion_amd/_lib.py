@@ -59,8 +59,9 @@ _SIGNATURES = {
     "cer_pack_conv_weight": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cer_weight_norm_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "cer_weight_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
-    "cer_conv1d_wgrad": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
-    "cer_conv2d_wgrad": (c_int, [_P, _P, _P] + [c_int] * 12 + [_P]),
+    "cer_conv_wgrad_workspace_bytes": (c_size_t, [ctypes.c_longlong, c_int, c_int, c_int]),
+    "cer_conv1d_wgrad": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
+    "cer_conv2d_wgrad": (c_int, [_P, _P, _P] + [c_int] * 12 + [_P, c_size_t, _P]),
     "cer_conv2d_wgrad_b3_workspace_bytes": (c_size_t, [c_int] * 7),
     "cer_conv2d_wgrad_b3": (c_int, [_P, _P, _P] + [c_int] * 12 + [_P, c_size_t, _P]),
     "cer_conv2d_wgrad_b3s": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 12 + [_P, c_size_t, _P]),

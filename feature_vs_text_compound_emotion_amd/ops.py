@@ -491,8 +491,11 @@ def conv2d_wgrad(dz, x, kh, kw, stride=1, pad=(0, 0), b3=False):
         check(lib.cer_conv2d_wgrad_b3(ptr(dz), ptr(x), ptr(dw), n, h, w, ho, wo, cout, cin, kh, kw, stride, pad[0], pad[1],
                                       ptr(ws), nbytes, current_stream()), "cer_conv2d_wgrad_b3")
         return dw
-    check(_lib.load().cer_conv2d_wgrad(ptr(dz), ptr(x), ptr(dw), n, h, w, ho, wo, cout, cin, kh, kw, stride, pad[0], pad[1],
-                                       current_stream()), "cer_conv2d_wgrad")
+    lib = _lib.load()
+    nbytes = lib.cer_conv_wgrad_workspace_bytes(n * ho * wo, cout, cin, kh * kw)
+    ws = _empty((nbytes // 4,), dz) if nbytes else None
+    check(lib.cer_conv2d_wgrad(ptr(dz), ptr(x), ptr(dw), n, h, w, ho, wo, cout, cin, kh, kw, stride, pad[0], pad[1],
+                               ptr(ws), nbytes, current_stream()), "cer_conv2d_wgrad")
     return dw
 
 
@@ -687,8 +690,11 @@ def conv1d_wgrad(dz, x, seq_len, k, dil):
     if r != r2:
         raise ValueError("dz and x must have the same number of rows")
     dw = _empty((cout, cin, k), dz)
-    check(_lib.load().cer_conv1d_wgrad(ptr(dz), dz_ld, ptr(x), x_ld, ptr(dw), r, seq_len, cout, cin, k, dil,
-                                       current_stream()), "cer_conv1d_wgrad")
+    lib = _lib.load()
+    nbytes = lib.cer_conv_wgrad_workspace_bytes(r, cout, cin, k)
+    ws = _empty((nbytes // 4,), dz) if nbytes else None
+    check(lib.cer_conv1d_wgrad(ptr(dz), dz_ld, ptr(x), x_ld, ptr(dw), r, seq_len, cout, cin, k, dil, ptr(ws), nbytes,
+                               current_stream()), "cer_conv1d_wgrad")
     return dw
 
 

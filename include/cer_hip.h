@@ -200,14 +200,18 @@ int cer_weight_norm_bwd(const float *dw, const float *v, const float *g, const f
 /* Weight gradient of the causal dilated conv1d / linear layers:
  * dW[co][ci][j] = sum_r dZ[r][co] * X[r-(k-1-j)*dil][ci], rows never cross a length-L sequence.
  * dz [R,dz_ld], x [R,x_ld], dw [Cout,Cin,k] (torch layout).  Linear: k = 1. */
+/* workspace (optional; both kernels below): with cer_conv_wgrad_workspace_bytes(R, Cout, Cin, k) bytes the rows are split over
+ * blocks and the partial results added in a fixed order (the tail's layers have R = B * L = 1024 rows and few output tiles);
+ * without it (NULL / too small) one block per tile and tap walks all rows. */
+size_t cer_conv_wgrad_workspace_bytes(long long R, int Cout, int Cin, int k);
 int cer_conv1d_wgrad(const float *dz, int dz_ld, const float *x, int x_ld, float *dw,
-                     int R, int L, int Cout, int Cin, int k, int dil, void *stream);
+                     int R, int L, int Cout, int Cin, int k, int dil, void *workspace, size_t workspace_bytes, void *stream);
 
 /* 2-D weight gradient (encoder units released for training, reference base/parameter_control.py:55-103):
  * dW[co][ci][kh][kw] = sum over output pixels (n,ho,wo) of dZ[n,ho,wo,co] * X[n, ho*stride-pad_t+kh, wo*stride-pad_l+kw, ci]
  * (zero outside the image).  dz dense [N*Ho*Wo, Cout], x dense NHWC, dw in torch's OIHW layout. */
 int cer_conv2d_wgrad(const float *dz, const float *x, float *dw, int N, int H, int W, int Ho, int Wo, int Cout, int Cin,
-                     int KH, int KW, int stride, int pad_t, int pad_l, void *stream);
+                     int KH, int KW, int stride, int pad_t, int pad_l, void *workspace, size_t workspace_bytes, void *stream);
 /* The same on the bf16 matrix cores with split hi/lo operands ("bf16x3": three MFMAs per product, <= 2^-15 relative per
  * product, fp32 accumulation), the pixel range split over blocks and reduced in a fixed order: the weight gradient of the
  * reference's released encoder units (base/parameter_control.py:55-103 un-freezes IR-50 stage 4 and half of stage 3; their
