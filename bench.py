@@ -42,7 +42,8 @@ KERNEL_NAMES = {41: "cer::conv_b3_dma16_kernel<128, 128, 2, 2, 4, 2>", 42: "cer:
                 57: "cer::conv_b3_patch_kernel<64, 4, 2>", 58: "cer::conv_b3_patch_kernel<128, 4, 2>",
                 71: "cer::conv_n16_patch_kernel<64, 4, 1, 1, {f16}, false>", 72: "cer::conv_n16_patch_kernel<128, 4, 2, 2, {f16}, false>",
                 78: "cer::conv_n16_patch_kernel<128, 4, 2, 2, {f16}, true>",
-                73: "cer::conv_n16_win_kernel<64, 4, 2, {f16}, false>", 76: "cer::conv_n16_win_kernel<128, 4, 2, {f16}, true>",
+                73: "cer::conv_n16_win_kernel<64, 4, 2, {f16}, false, 2>", 76: "cer::conv_n16_win_kernel<128, 4, 2, {f16}, true, 2>",
+                77: "cer::conv_n16_win_kernel<64, 4, 1, {f16}, false, 1>",
                 91: "cer::conv_n16_kernel<256, 256, 2, 4, {f16}, 2>", 94: "cer::conv_n16_kernel<128, 128, 2, 2, {f16}, 2>",
                 63: "cer::conv_n16_kernel<256, 64, 4, 1, {f16}, 1>", 64: "cer::conv_n16_kernel<128, 128, 2, 2, {f16}, 1>",
                 65: "cer::conv_n16_kernel<128, 64, 2, 2, {f16}, 1>", 66: "cer::conv_n16_kernel<64, 64, 2, 2, {f16}, 1>",

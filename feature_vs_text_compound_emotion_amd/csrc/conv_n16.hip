@@ -363,7 +363,8 @@ static int launch_n16(const ConvArgs &a, hipStream_t st) {
 // (4 waves each), 91 = 256x256 (8 waves) and 94 = 128x128 with the step's DMA pieces spread over the first half of the MFMA
 // groups; window-resident kernels (conv_n16_patch.hip, 3x3 / stride 1 / pad 1): patches of 16x16 pixels (H, W % 16 == 0):
 // 71 = 64 couts (Cin == 64, 4 waves, two blocks per CU), 72 = 128 couts, 78 = 128 couts with ping-pong phases; 1-D windows of
-// 256 consecutive pixels (any image size with W <= 86): 73 = 64 couts, 76 = 128 couts with ping-pong phases.
+// 256 consecutive pixels (any image size with W <= 86): 73 = 64 couts, 76 = 128 couts with ping-pong phases, 77 = 64 couts,
+// Cin == 64, ONE window buffer, 4 waves (two blocks per CU).
 static bool patch_geometry(const cer_conv_desc *d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil_h == 1 && d->dil_w == 1 && d->pad_t == 1 && d->pad_l == 1 &&
            d->Ho == d->H && d->Wo == d->W && (d->H & 15) == 0 && (d->W & 15) == 0 && (d->Cin & 63) == 0 && d->split_k <= 1;
@@ -385,7 +386,9 @@ int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         else if (win_geometry(d) && t256 >= 64) {
             // one block per CU (the windows fill the LDS): whole rounds of 256 blocks; a 128-cout block does twice the work of
             // a 64-cout block in 1.68x the time (fp16, 1024 frames: 56x56 875 -> 957, 28x28 1066 -> 1158, 5x5 720 -> 939 TF/s)
-            tile = Cout > 64 ? 76 : 73;   // 76: ping-pong variant of 74; measured per shape at 40x40 and 224x224 input (tools/bench_conv.py)
+            // measured per shape at 40x40, 80x80 and 224x224 input (tools/bench_conv.py): Cin == 64 -> the single-window tile (two
+            // blocks per CU: 64 -> 64 @40x40 448 -> 565 TF/s, 64 -> 128 645 -> 677); else 128 couts with ping-pong phases, or 64
+            tile = d->Cin == 64 ? 77 : (Cout > 64 ? 76 : 73);
         }
         else if (Cout <= 64) tile = t256 >= 512 ? 63 : ((M + 127) / 128 >= 256 ? 65 : 66);
         else if (Cout <= 128) tile = (M + 127) / 128 >= 256 ? 64 : 67;
@@ -403,7 +406,7 @@ int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         case 67: bm = 64; bn = 128; break;
         case 71: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels
         case 72: case 78: bm = 256; bn = 128; break;   // (78: ping-pong phases)
-        case 73: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels
+        case 73: case 77: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels (77: Cin == 64, one window)
         case 76: bm = 256; bn = 128; break;   // (ping-pong phases)
         default: return 0;
     }
@@ -417,7 +420,7 @@ int conv_n16_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 65: return launch_n16<128, 64, 2, 2>(a, st);
         case 66: return launch_n16<64, 64, 2, 2>(a, st);
         case 67: return launch_n16<64, 128, 1, 4>(a, st);
-        case 71: case 72: case 73: case 76: case 78: return conv_n16_patch_launch(tile, a, st);
+        case 71: case 72: case 73: case 76: case 77: case 78: return conv_n16_patch_launch(tile, a, st);
         case 91: return launch_n16<256, 256, 2, 4, 2>(a, st);
         case 94: return launch_n16<128, 128, 2, 2, 2>(a, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (narrow): unknown tile id");

@@ -305,7 +305,9 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
 // READ phase (all 16 fragment reads + the step's DMA issue) and an MFMA phase (32 MFMAs, nothing else) with a block barrier
 // after each, and group 1 starts one phase late, so one wave of a SIMD streams MFMAs while the other fetches.  Each group DMAs
 // the weight rows of its own cout half (the other group never reads them): both keep the ring's two-step latency budget.
-template <int BN, int WP, int WC, bool F16, bool PP>
+// XBUFS = 1: ONE window buffer (Cin == 64: a single chunk, nothing to prefetch) -- with 4 waves and 64 couts a block needs
+// NP + 25 KiB, so two blocks share a CU and overlap each other's window fetch and epilogue (the 64 -> 64 layers at 40 x 40).
+template <int BN, int WP, int WC, bool F16, bool PP, int XBUFS>
 __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs p, int NP) {
     constexpr int NW = WP * WC, NT = NW * 64, BM = 256;
     constexpr int NPMAX = 54;                                       // 8-row window pieces per buffer the LDS can hold twice (W <= 86)
@@ -314,13 +316,13 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
     static_assert(BN % (8 * NW) == 0, "weight-slice pieces are dealt round-robin to the waves");
     constexpr int WQ = BN / (8 * NW);
     constexpr int TP = BM / (16 * WP), TC = BN / (16 * WC);
-    static_assert(XPW <= 9 && TP >= 2, "geometry");
+    static_assert((XBUFS == 1 || XPW <= 9) && TP >= 2 && (XBUFS == 2 || !PP), "geometry");
     static_assert(!PP || (WP == 4 && WC == 2 && (BN / 16) % 4 == 0), "ping-pong: waves w and w + 4 share a SIMD and split the couts");
     constexpr unsigned OOB = 0x80000000u;
     constexpr int NGRP = 2 * TP;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_n16p[];
     unsigned char *smem = reinterpret_cast<unsigned char *>(smem_n16p);
-    const int XBYTES = NP * 1024, WOFF = 2 * XBYTES, SINK = WOFF + RING * WSLICE;
+    const int XBYTES = NP * 1024, WOFF = XBUFS * XBYTES, SINK = WOFF + RING * WSLICE;
     const int ZROW = NP * 8 - 1;                                    // past the rows the taps address: always zero-filled
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
     auto issue_x = [&](int i, int cc) {
         const bool real = x_real[i] && cc < cin_steps;
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xwin) + (size_t)cc * 128, 0, (int)OOB, 0x00020000);
-        unsigned char *dst = real ? smem + (cc & 1) * XBYTES + (wave + NW * i) * 1024 : smem + SINK;
+        unsigned char *dst = real ? smem + (XBUFS == 2 ? (cc & 1) * XBYTES : 0) + (wave + NW * i) * 1024 : smem + SINK;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (n_lds_ptr_t)dst, 16, (int)(real ? x_off[i] : OOB), 0, 0, 0);
     };
     auto issue_w = [&](int cc, int tap, int ring) {
@@ -422,13 +424,13 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
     }
 
     for (int cc = 0; cc < cin_steps; ++cc) {
-        const int xcur = (cc & 1) * XBYTES;
+        const int xcur = XBUFS == 2 ? (cc & 1) * XBYTES : 0;
         static_for<9>([&](auto T) {
             constexpr int tap = decltype(T)::v, kh = tap / 3, kw = tap % 3;
-            constexpr bool XWIN2 = true;
+            constexpr bool XWIN2 = XBUFS == 2;
             if constexpr (!PP) {
                 constexpr int ptap = (tap + 8) % 9;
-                constexpr int pcnt = WQ + (ptap < XPW ? 1 : 0);
+                constexpr int pcnt = WQ + ((XWIN2 && ptap < XPW) ? 1 : 0);
                 if (cc == 0 && tap == 0) {
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");
                 } else {
@@ -490,7 +492,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
                     for (int a = 0; a < TC; ++a) af[1][a] = lda(a, 1);
                 }
                 if constexpr (g == 0) issue_w(ncc, ntap, nring);
-                if constexpr (g == 2 % NGRP && tap < XPW) issue_x(tap, cc + 1);
+                if constexpr (g == 2 % NGRP && XWIN2 && tap < XPW) issue_x(tap, cc + 1);
 #pragma unroll
                 for (int a = 0; a < TC; ++a) acc[a][b] = mfma_n16<F16>(af[kk][a], bf[g], acc[a][b]);
             });
@@ -500,7 +502,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
                 __builtin_amdgcn_sched_group_barrier(0x008, TC, 0);
                 constexpr int nread = (g + 2 < NGRP ? 1 : 0) + (g == 0 ? TC : 0);
                 if constexpr (nread > 0) __builtin_amdgcn_sched_group_barrier(0x100, nread, 0);
-                constexpr int npiece = (g == 0 ? WQ : 0) + ((g == 2 % NGRP && tap < XPW) ? 1 : 0);
+                constexpr int npiece = (g == 0 ? WQ : 0) + ((g == 2 % NGRP && XWIN2 && tap < XPW) ? 1 : 0);
                 if constexpr (npiece > 0) __builtin_amdgcn_sched_group_barrier(0x010, npiece, 0);
             });
             }
@@ -590,18 +592,18 @@ static int n16_win_pieces(const ConvArgs &a) {
     return np <= 54 ? np : 0;
 }
 
-template <int BN, int WP, int WC, bool PP>
+template <int BN, int WP, int WC, bool PP, int XBUFS = 2>
 static int launch_win(const ConvArgs &a, hipStream_t st) {
     const int np = n16_win_pieces(a);
-    size_t lds = (size_t)2 * np * 1024 + 3 * (size_t)BN * 128 + 1024;
+    size_t lds = (size_t)XBUFS * np * 1024 + 3 * (size_t)BN * 128 + 1024;
     if (lds < (size_t)256 * BN * 4) lds = (size_t)256 * BN * 4;   // the epilogue's accumulator tile
     const dim3 grid(a.tiles_m * a.tiles_n, 1, 1), block(WP * WC * 64);
     if (a.narrow == CER_STORE_F16) {
-        auto k = conv_n16_win_kernel<BN, WP, WC, true, PP>;
+        auto k = conv_n16_win_kernel<BN, WP, WC, true, PP, XBUFS>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CER_LAUNCH(k, grid, block, lds, st, a, np);
     } else {
-        auto k = conv_n16_win_kernel<BN, WP, WC, false, PP>;
+        auto k = conv_n16_win_kernel<BN, WP, WC, false, PP, XBUFS>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         CER_LAUNCH(k, grid, block, lds, st, a, np);
     }
@@ -646,6 +648,12 @@ bool conv_n16_patch_ok(const ConvArgs &a, int tile) {
 }
 
 int conv_n16_patch_launch(int tile, const ConvArgs &a, hipStream_t st) {
+    if (tile == 77) {
+        if (!conv_n16_win_ok(a) || a.Cin != 64)
+            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow, single-window kernel): needs a 3x3 / stride 1 / pad 1 conv with "
+                                                       "W <= 86 and Cin == 64, no split-K");
+        return launch_win<64, 4, 1, false, 1>(a, st);
+    }
     if (tile == 73 || tile == 76) {
         if (!conv_n16_win_ok(a))
             return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow, window kernel): needs a 3x3 / stride 1 / pad 1 conv with W <= 86, "

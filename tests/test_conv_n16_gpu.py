@@ -66,7 +66,9 @@ def test_to_n16_is_round_to_nearest_even_and_from_n16_is_exact():
     (3, 64, 64, 40, 3, 1, 73), (2, 64, 128, 20, 3, 1, 73), (5, 128, 40, 10, 3, 1, 73), (7, 64, 64, 5, 3, 1, 73),
     (1, 64, 64, 56, 3, 1, 73), (50, 64, 64, 2, 3, 1, 73), (3, 64, 64, 3, 3, 1, 73),
     (2, 128, 128, 56, 3, 1, 76), (3, 256, 256, 28, 3, 1, 76), (5, 128, 200, 14, 3, 1, 76), (9, 512, 512, 7, 3, 1, 76),
-    (2, 64, 128, 40, 3, 1, 76), (1, 64, 128, 86, 3, 1, 76), (1, 64, 128, 17, 3, 1, 76)])
+    (2, 64, 128, 40, 3, 1, 76), (1, 64, 128, 86, 3, 1, 76), (1, 64, 128, 17, 3, 1, 76),
+    # single-window tile (Cin == 64, 4 waves, two blocks per CU)
+    (3, 64, 64, 40, 3, 1, 77), (7, 64, 64, 5, 3, 1, 77), (1, 64, 40, 56, 3, 1, 77), (50, 64, 64, 2, 3, 1, 77), (1, 64, 128, 86, 3, 1, 77)])
 def test_conv_n16_matches_float64_on_the_same_operands(n, cin, cout, hw, k, stride, tile, dtype):
     from feature_vs_text_compound_emotion_amd import ops
     x, w = _setup(n, cin, cout, hw, k, n * 100 + cin + cout, dtype)
