@@ -28,7 +28,10 @@ namespace cer {
 constexpr unsigned long long B3_PATCH_F_TABLE = 0xaaa00a00ull;
 __device__ __forceinline__ int b3_patch_f(int wx) { return (int)((B3_PATCH_F_TABLE >> (2 * wx)) & 3ull); }
 
-template <int BN, int WP, int WC>
+// SINGLE: 4 waves (WC = 1, each wave 64 pixels x 64 couts), ONE window buffer that is re-filled at every chunk boundary, the
+// single-phase step (reads two MFMA groups ahead, DMA between MFMA groups, one barrier per step): 67 KiB of LDS, so TWO blocks
+// share a CU and cover each other's window fetches and epilogue -- the K-short 64-cout layers.
+template <int BN, int WP, int WC, bool SINGLE>
 __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs p) {
     constexpr int NW = WP * WC, NT = NW * 64;
     constexpr int PH = 16, PWD = 16, WW = 18, WROWS = 18 * 18;
@@ -40,9 +43,9 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
     static_assert(WPIECES % NW == 0, "weight-slice pieces are dealt round-robin to the waves");
     constexpr int WQ = WPIECES / NW;                              // weight pieces per wave and step
     constexpr int TP = PH / WP, TC = BN / (16 * WC);
-    static_assert(PH % WP == 0 && XPW <= 9 && TP >= 2, "geometry");
-    static_assert(WP == 4 && WC == 2 && (BN / 16) % 4 == 0, "ping-pong: waves w and w + 4 share a SIMD and split the couts");
-    constexpr int WOFF = 2 * XBYTES, SINK = WOFF + 3 * WSLICE;    // LDS map: two windows | weight ring | 1 KiB sink
+    static_assert(PH % WP == 0 && (SINGLE || XPW <= 9) && TP >= 2, "geometry");
+    static_assert(SINGLE ? WC == 1 : (WP == 4 && WC == 2 && (BN / 16) % 4 == 0), "ping-pong: waves w and w + 4 share a SIMD and split the couts");
+    constexpr int WOFF = (SINGLE ? 1 : 2) * XBYTES, SINK = WOFF + 3 * WSLICE;    // LDS map: window(s) | weight ring | 1 KiB sink
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_b3p[];
     unsigned char *smem = reinterpret_cast<unsigned char *>(smem_b3p);
@@ -83,10 +86,10 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
 #pragma unroll
     for (int i = 0; i < WQ; ++i) {
         // the group's own cout half, BN / 32 pieces per plane dealt to its four waves
-        const int j = (wave & 3) + 4 * i;
-        constexpr int PPL = BN / 32;                                // pieces per plane in this group's pool
+        const int j = SINGLE ? wave + NW * i : (wave & 3) + 4 * i;
+        constexpr int PPL = SINGLE ? BN / 16 : BN / 32;             // pieces per plane in this wave's pool
         w_plane[i] = j / PPL;
-        const int pc = (wave >> 2) * PPL + j % PPL;                 // piece (16 cout rows) within the plane
+        const int pc = (SINGLE ? 0 : (wave >> 2) * PPL) + j % PPL;  // piece (16 cout rows) within the plane
         const int row = pc * 16 + prow;
         w_dst[i] = w_plane[i] * WPL + pc * 1024;
         w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ swz16((row >> 2) & 3)) << 3)) * 2) : OOB;
@@ -102,7 +105,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
         const bool real = x_real[i] && cc < cin_steps;
         const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xh) + (size_t)cc * 64, 0, (int)OOB, 0x00020000);
         const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xl) + (size_t)cc * 64, 0, (int)OOB, 0x00020000);
-        unsigned char *dst = real ? smem + (cc & 1) * XBYTES + (wave + NW * i) * 1024 : smem + SINK;
+        unsigned char *dst = real ? smem + (SINGLE ? 0 : (cc & 1) * XBYTES) + (wave + NW * i) * 1024 : smem + SINK;
         const int vo = (int)(real ? x_off[i] : OOB);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_ptr_t)(real ? dst + XPL : dst), 16, vo, 0, 0, 0);
@@ -139,15 +142,27 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
     for (int i = 0; i < XPW; ++i) issue_x(i, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WQ) : "memory");   // the window and slice 0 (slice 1 may still be in flight)
-    __builtin_amdgcn_s_barrier();
-    if (wc == 1) __builtin_amdgcn_s_barrier();                  // group 1 runs one phase behind group 0
+    if constexpr (!SINGLE) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WQ) : "memory");   // the window and slice 0 (slice 1 may still be in flight)
+        __builtin_amdgcn_s_barrier();
+        if (wc == 1) __builtin_amdgcn_s_barrier();                  // group 1 runs one phase behind group 0
+    }
 
     // One step = one filter tap of one 32-channel chunk; per wave and step WQ weight pieces (slice of step s + 2) and, during
     // taps 0 .. XPW-1, the two planes of one window piece of the next chunk.  At the top of step s everything issued before
     // step s-1 must have landed: vmcnt(pieces of the previous step).
     for (int cc = 0; cc < cin_steps; ++cc) {
-        const int xcur = (cc & 1) * XBYTES;
+        const int xcur = SINGLE ? 0 : (cc & 1) * XBYTES;
+        if constexpr (SINGLE) {
+            if (cc > 0) {   // everyone is done with the previous chunk's window: re-fill the one buffer (the other block computes meanwhile)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int i = 0; i < XPW; ++i) issue_x(i, cc);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
         static_for<9>([&](auto T) {
             constexpr int tap = decltype(T)::v, kh = tap / 3, kw = tap % 3;
             constexpr int ntap = (tap + 2) % 9, nring = (tap + 2) % 3;
@@ -158,7 +173,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
             // drop the kernel stub)
             auto lda = [&](int a, int pl) { return *reinterpret_cast<const u32x4 *>(Wr + pl * WPL + arow + a * 16 * 64); };
             auto ldb = [&](int b, int pl) { return *reinterpret_cast<const u32x4 *>(Xb + pl * XPL + bcol[kw] + b * WP * WW * 64); };
-            {
+            if constexpr (!SINGLE) {
                 // ---- READ phase: every fragment of the step, then the step's DMA (slice of step + 2, a window piece) ----
                 u32x4 ah[TC], al[TC], bh[TP], bl[TP];
 #pragma unroll
@@ -194,10 +209,44 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+            } else {
+                // single-phase step: at its top the slice of this step has landed (issued two steps ago); the step issues the
+                // slice of step + 2 after its first MFMA group
+                if (cc == 0 && tap == 0) {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");  // prologue: all but slice 1
+                } else {
+                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");
+                }
+                __builtin_amdgcn_s_barrier();
+                u32x4 ah[TC], al[TC], bh[TP], bl[TP];
+#pragma unroll
+                for (int a = 0; a < TC; ++a) { ah[a] = lda(a, 0); al[a] = lda(a, 1); }
+                bh[0] = ldb(0, 0); bl[0] = ldb(0, 1);
+                bh[1] = ldb(1, 0); bl[1] = ldb(1, 1);
+                static_for<TP>([&](auto G) {
+                    constexpr int g = decltype(G)::v;
+                    if constexpr (g + 2 < TP) { bh[g + 2] = ldb(g + 2, 0); bl[g + 2] = ldb(g + 2, 1); }
+                    if constexpr (g == 0) issue_w(ncc, ntap, nring);
+#pragma unroll
+                    for (int a = 0; a < TC; ++a) {
+                        acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
+                        acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bl[g]), acc[a][g], 0, 0, 0);
+                        acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
+                    }
+                });
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * TC + 4, 0);
+                static_for<TP>([&](auto G) {
+                    constexpr int g = decltype(G)::v;
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * TC, 0);
+                    if constexpr (g + 2 < TP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if constexpr (g == 0) __builtin_amdgcn_sched_group_barrier(0x010, WQ, 0);
+                });
             }
         });
     }
-    if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
+    if constexpr (!SINGLE) {
+        if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sink pieces of the last steps
 
     // ---- epilogue: accumulators -> LDS (fp32, swizzled granules) -> compact coalesced loop, one patch row per iteration ----
@@ -549,10 +598,10 @@ static int launch_b3_win(const ConvArgs &a, hipStream_t st) {
     return CER_OK;
 }
 
-template <int BN, int WP, int WC>
+template <int BN, int WP, int WC, bool SINGLE = false>
 static int launch_b3_patch(const ConvArgs &a, hipStream_t st) {
-    const size_t lds = (size_t)2 * 2 * 21 * 1024 + 3 * (size_t)2 * BN * 64 + 1024;
-    auto k = conv_b3_patch_kernel<BN, WP, WC>;
+    const size_t lds = (size_t)(SINGLE ? 1 : 2) * 2 * 21 * 1024 + 3 * (size_t)2 * BN * 64 + 1024;
+    auto k = conv_b3_patch_kernel<BN, WP, WC, SINGLE>;
     if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, 1), dim3(WP * WC * 64), lds, st, a);
     CER_HIP_CHECK(hipGetLastError());
@@ -584,6 +633,7 @@ int conv_b3_patch_launch(int tile, const ConvArgs &a, hipStream_t st) {
         return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3, patch kernel): needs a 3x3 / stride 1 / pad 1 conv on images whose "
                                                    "height and width are multiples of 16, Cin % 32 == 0, no split-K");
     switch (tile) {
+        case 59: return launch_b3_patch<64, 4, 1, true>(a, st);      // single-phase, one window buffer, two blocks per CU
         case 57: return launch_b3_patch<64, 4, 2>(a, st);
         case 58: return launch_b3_patch<128, 4, 2>(a, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3, patch kernel): unknown tile id");

@@ -36,6 +36,8 @@ def test_split_is_round_to_nearest_and_exact_to_16_bits():
     # patches per image, ragged Cout, 1 / 2 / 4 / 8 channel chunks of 32, two cout tiles per patch
     (2, 64, 64, 32, 3, 1, 57), (1, 64, 128, 48, 3, 1, 57), (2, 32, 40, 16, 3, 1, 57), (3, 128, 64, 16, 3, 1, 57),
     (2, 128, 128, 32, 3, 1, 58), (1, 128, 256, 32, 3, 1, 58), (1, 256, 128, 16, 3, 1, 58), (3, 64, 100, 32, 3, 1, 58),
+    # 4 waves, one window buffer re-filled per chunk, two blocks per CU
+    (2, 64, 64, 32, 3, 1, 59), (1, 64, 128, 48, 3, 1, 59), (2, 32, 40, 16, 3, 1, 59), (3, 128, 64, 16, 3, 1, 59), (1, 256, 64, 16, 3, 1, 59),
     # 1-D window kernels (any image size; 256 consecutive pixels span image rows and images): the reference's 40x40 crop
     # pyramid (40 / 20 / 10 / 5), the 224x224 pyramid's 56 / 28 / 14 / 7, tiny images (many per tile), ragged M and Cout,
     # the widest image the LDS takes (86)
@@ -85,7 +87,7 @@ def test_conv_b3_fused_epilogue_outputs(tile):
     assert (st[1] - (raw * raw).sum((0, 2, 3))).abs().max().item() < 1e-2
 
 
-@pytest.mark.parametrize("cin,cout,tile", [(64, 64, 57), (64, 128, 58), (128, 200, 58), (64, 64, 0), (128, 128, 0),
+@pytest.mark.parametrize("cin,cout,tile", [(64, 64, 57), (64, 128, 58), (128, 200, 58), (64, 64, 59), (64, 64, 0), (128, 128, 0),
                                            (64, 64, 55), (64, 128, 56), (128, 200, 56)])
 def test_conv_b3_patch_kernel_epilogue_on_non_square_images(cin, cout, tile):
     """bf16x3 patch kernels: H != W, bias9 (folded input BatchNorm) + PReLU + split residual + statistics; tile 0 on a shape
