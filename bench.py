@@ -38,9 +38,8 @@ NARROW = ("bf16", "fp16")
 KERNEL_NAMES = {41: "cer::conv_b3_dma16_kernel<128, 128, 2, 2, 4, 2>", 42: "cer::conv_b3_dma16_kernel<128, 64, 2, 2, 4, 2>",
                 44: "cer::conv_b3_dma16_kernel<64, 128, 1, 4, 4, 2>", 45: "cer::conv_b3_dma16_kernel<64, 64, 2, 2, 4, 2>",
                 48: "cer::conv_b3_dma16_kernel<256, 64, 4, 1, 4, 2>",
-                55: "cer::conv_b3_win_kernel<64, 4, 2>", 56: "cer::conv_b3_win_kernel<128, 4, 2>",
-                57: "cer::conv_b3_patch_kernel<64, 4, 2, false>", 58: "cer::conv_b3_patch_kernel<128, 4, 2, false>",
-                59: "cer::conv_b3_patch_kernel<64, 4, 1, true>",
+                53: "cer::conv_b3_win_kernel<64, 4, 1, true>", 56: "cer::conv_b3_win_kernel<128, 4, 2, false>",
+                58: "cer::conv_b3_patch_kernel<128, 4, 2, false>", 59: "cer::conv_b3_patch_kernel<64, 4, 1, true>",
                 71: "cer::conv_n16_patch_kernel<64, 4, 1, 1, {f16}, false>", 72: "cer::conv_n16_patch_kernel<128, 4, 2, 2, {f16}, false>",
                 78: "cer::conv_n16_patch_kernel<128, 4, 2, 2, {f16}, true>",
                 73: "cer::conv_n16_win_kernel<64, 4, 2, {f16}, false, 2>", 76: "cer::conv_n16_win_kernel<128, 4, 2, {f16}, true, 2>",

@@ -376,8 +376,8 @@ static int launch_b3_dma16(const ConvArgs &a, hipStream_t st) {
 
 // tile ids (desc.tile): 0 auto; 41/42/44/45 = 128x128 / 128x64 / 64x128 / 64x64 (4 waves, two LDS stages);
 // 48 = 256x64 (4 waves x (64 pixels x 64 couts)) for Cout <= 64 at large M; window-resident kernels (conv_b3_patch.hip, 3x3 /
-// stride 1 / pad 1): 57 / 58 = 16x16 patches x 64 / 128 couts (H, W % 16 == 0; 59 = 64 couts on 4 waves with ONE window buffer
-// re-filled per chunk, two blocks per CU), 55 / 56 = 1-D windows of 256 consecutive
+// stride 1 / pad 1): 16x16 patches (H, W % 16 == 0): 58 = 128 couts (8 waves, ping-pong phases), 59 = 64 couts on 4 waves with ONE
+// window buffer re-filled per chunk (two blocks per CU); 1-D windows of 256 consecutive
 // pixels x 64 / 128 couts (any image size with W <= 86).
 static bool b3_patch_geometry(const cer_conv_desc *d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil_h == 1 && d->dil_w == 1 && d->pad_t == 1 && d->pad_l == 1 &&
@@ -398,7 +398,7 @@ int conv_b3_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         const long long t128 = (M + 127) / 128 * ((Cout + 127) / 128), t256 = (M + 255) / 256;
         if (b3_patch_geometry(d) && Cout <= 64 && t256 >= 512) tile = 59;   // 4 waves, one window, two blocks per CU: 64 -> 64 @224x224 300 -> 341 TF/s
         else if (b3_patch_geometry(d) && Cout >= 128 && t256 * ((Cout + 127) / 128) >= 512) tile = 58;
-        else if (b3_win_geometry(d) && t256 >= 64) tile = Cout > 64 ? 56 : 55;   // ping-pong window kernels: measured per shape at
+        else if (b3_win_geometry(d) && t256 >= 64) tile = Cout > 64 ? 56 : 53;   // ping-pong window kernels: measured per shape at
                                                                                  // 40x40, 80x80 and 224x224 input (tools/bench_conv.py)
         else if (Cout <= 64) tile = t256 >= 512 ? 48 : 42;  // 256x64: 226 vs 204 TF/s on 64->64 @224x224
         else if (t128 >= 512) tile = 41;
@@ -411,9 +411,9 @@ int conv_b3_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         case 44: bm = 64; bn = 128; break;
         case 45: bm = 64; bn = 64; break;
         case 48: bm = 256; bn = 64; break;
-        case 57: case 59: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels (59: 4 waves, one window, two blocks per CU)
+        case 59: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels (4 waves, one window, two blocks per CU)
         case 58: bm = 256; bn = 128; break;
-        case 55: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels
+        case 53: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels (53: 4 waves, one window)
         case 56: bm = 256; bn = 128; break;
         default: return 0;
     }
@@ -427,7 +427,7 @@ int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 44: return launch_b3_dma16<64, 128, 1, 4>(a, st);
         case 45: return launch_b3_dma16<64, 64, 2, 2>(a, st);
         case 48: return launch_b3_dma16<256, 64, 4, 1>(a, st);
-        case 55: case 56: case 57: case 58: case 59: return conv_b3_patch_launch(tile, a, st);
+        case 53: case 56: case 58: case 59: return conv_b3_patch_launch(tile, a, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3): unknown tile id");
     }
 }

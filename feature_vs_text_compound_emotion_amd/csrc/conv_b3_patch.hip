@@ -324,7 +324,8 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
 // such a lane reads the window's last row, which the DMA zero-fills.  Fragment rows start at any alignment; the swizzle
 // slot = chunk ^ ((row & 4) >> 1) is conflict free for every alignment (tools/check_swizzle.py).  Everything else -- weight
 // ring, counted vmcnt, unrolled taps, ping-pong phases -- is the patch kernel's.
-template <int BN, int WP, int WC>
+// SINGLE: as in conv_b3_patch_kernel -- 4 waves, one window buffer re-filled per chunk, single-phase steps, two blocks per CU.
+template <int BN, int WP, int WC, bool SINGLE>
 __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p, int NP) {
     constexpr int NW = WP * WC, NT = NW * 64, BM = 256;
     constexpr int NPMAX = 27;                                     // window pieces (16 rows) per plane the LDS can hold twice
@@ -333,12 +334,12 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
     static_assert(WPIECES % NW == 0, "weight-slice pieces are dealt round-robin to the waves");
     constexpr int WQ = WPIECES / NW;
     constexpr int TP = BM / (16 * WP), TC = BN / (16 * WC);
-    static_assert(XPW <= 9 && TP >= 2, "geometry");
-    static_assert(WP == 4 && WC == 2 && (BN / 16) % 4 == 0, "ping-pong: waves w and w + 4 share a SIMD and split the couts");
+    static_assert((SINGLE || XPW <= 9) && TP >= 2, "geometry");
+    static_assert(SINGLE ? WC == 1 : (WP == 4 && WC == 2 && (BN / 16) % 4 == 0), "ping-pong: waves w and w + 4 share a SIMD and split the couts");
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_b3p[];
     unsigned char *smem = reinterpret_cast<unsigned char *>(smem_b3p);
-    const int XPL = NP * 1024, XBYTES = 2 * XPL, WOFF = 2 * XBYTES, SINK = WOFF + 3 * WSLICE;
+    const int XPL = NP * 1024, XBYTES = 2 * XPL, WOFF = (SINGLE ? 1 : 2) * XBYTES, SINK = WOFF + 3 * WSLICE;
     const int ZROW = NP * 16 - 1;                                 // always zero-filled by the DMA
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -376,10 +377,10 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
 #pragma unroll
     for (int i = 0; i < WQ; ++i) {
         // the group's own cout half, BN / 32 pieces per plane dealt to its four waves
-        const int j = (wave & 3) + 4 * i;
-        constexpr int PPL = BN / 32;                                // pieces per plane in this group's pool
+        const int j = SINGLE ? wave + NW * i : (wave & 3) + 4 * i;
+        constexpr int PPL = SINGLE ? BN / 16 : BN / 32;             // pieces per plane in this wave's pool
         w_plane[i] = j / PPL;
-        const int pc = (wave >> 2) * PPL + j % PPL;                 // piece (16 cout rows) within the plane
+        const int pc = (SINGLE ? 0 : (wave >> 2) * PPL) + j % PPL;  // piece (16 cout rows) within the plane
         const int row = pc * 16 + prow;
         w_dst[i] = w_plane[i] * WPL + pc * 1024;
         w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ swz16((row >> 2) & 3)) << 3)) * 2) : OOB;
@@ -394,7 +395,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
         const bool real = x_real[i] && cc < cin_steps;
         const __amdgpu_buffer_rsrc_t rh = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xh) + (size_t)cc * 64, 0, (int)OOB, 0x00020000);
         const __amdgpu_buffer_rsrc_t rl = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(xl) + (size_t)cc * 64, 0, (int)OOB, 0x00020000);
-        unsigned char *dst = real ? smem + (cc & 1) * XBYTES + (wave + NW * i) * 1024 : smem + SINK;
+        unsigned char *dst = real ? smem + (SINGLE ? 0 : (cc & 1) * XBYTES) + (wave + NW * i) * 1024 : smem + SINK;
         const int vo = (int)(real ? x_off[i] : OOB);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rh, (lds_ptr_t)dst, 16, vo, 0, 0, 0);
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rl, (lds_ptr_t)(real ? dst + XPL : dst), 16, vo, 0, 0, 0);
@@ -444,12 +445,24 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
     for (int i = 0; i < XPW; ++i) issue_x(i, 0);
     issue_w(0, 0, 0);
     issue_w(0, 1, 1);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WQ) : "memory");   // the window and slice 0 (slice 1 may still be in flight)
-    __builtin_amdgcn_s_barrier();
-    if (wc == 1) __builtin_amdgcn_s_barrier();                  // group 1 runs one phase behind group 0
+    if constexpr (!SINGLE) {
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WQ) : "memory");   // the window and slice 0 (slice 1 may still be in flight)
+        __builtin_amdgcn_s_barrier();
+        if (wc == 1) __builtin_amdgcn_s_barrier();                  // group 1 runs one phase behind group 0
+    }
 
     for (int cc = 0; cc < cin_steps; ++cc) {
-        const int xcur = (cc & 1) * XBYTES;
+        const int xcur = SINGLE ? 0 : (cc & 1) * XBYTES;
+        if constexpr (SINGLE) {
+            if (cc > 0) {   // everyone is done with the previous chunk's window: re-fill the one buffer (the other block computes meanwhile)
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+#pragma unroll
+                for (int i = 0; i < XPW; ++i) issue_x(i, cc);
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+        }
         static_for<9>([&](auto T) {
             constexpr int tap = decltype(T)::v, kh = tap / 3, kw = tap % 3;
             constexpr int ntap = (tap + 2) % 9, nring = (tap + 2) % 3;
@@ -465,7 +478,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
                 baddr[b] = row * 64 + ((kg ^ ((row & 4) >> 1)) << 4);
             }
             auto ldb = [&](int b, int pl) { return *reinterpret_cast<const u32x4 *>(Xb + pl * XPL + baddr[b]); };
-            {
+            if constexpr (!SINGLE) {
                 // ---- READ phase: every fragment of the step, then the step's DMA (slice of step + 2, a window piece) ----
                 u32x4 ah[TC], al[TC], bh[TP], bl[TP];
 #pragma unroll
@@ -501,10 +514,38 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
                 __builtin_amdgcn_sched_barrier(0);
                 __builtin_amdgcn_s_barrier();
                 __builtin_amdgcn_sched_barrier(0);
+            } else {
+                asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");   // this step's slice has landed
+                __builtin_amdgcn_s_barrier();
+                u32x4 ah[TC], al[TC], bh[TP], bl[TP];
+#pragma unroll
+                for (int a = 0; a < TC; ++a) { ah[a] = lda(a, 0); al[a] = lda(a, 1); }
+                bh[0] = ldb(0, 0); bl[0] = ldb(0, 1);
+                bh[1] = ldb(1, 0); bl[1] = ldb(1, 1);
+                static_for<TP>([&](auto G) {
+                    constexpr int g = decltype(G)::v;
+                    if constexpr (g + 2 < TP) { bh[g + 2] = ldb(g + 2, 0); bl[g + 2] = ldb(g + 2, 1); }
+                    if constexpr (g == 0) issue_w(ncc, ntap, nring);
+#pragma unroll
+                    for (int a = 0; a < TC; ++a) {
+                        acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(al[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
+                        acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bl[g]), acc[a][g], 0, 0, 0);
+                        acc[a][g] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16x8(ah[a]), as_bf16x8(bh[g]), acc[a][g], 0, 0, 0);
+                    }
+                });
+                __builtin_amdgcn_sched_group_barrier(0x100, 2 * TC + 4, 0);
+                static_for<TP>([&](auto G) {
+                    constexpr int g = decltype(G)::v;
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * TC, 0);
+                    if constexpr (g + 2 < TP) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+                    if constexpr (g == 0) __builtin_amdgcn_sched_group_barrier(0x010, WQ, 0);
+                });
             }
         });
     }
-    if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
+    if constexpr (!SINGLE) {
+        if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
     // ---- epilogue: accumulators -> LDS (fp32, swizzled granules) -> compact coalesced loop over consecutive output rows ----
@@ -586,12 +627,12 @@ static int b3_win_pieces(const ConvArgs &a) {
     return np <= 27 ? np : 0;                           // 4 * 27 KiB + the 48 KiB weight ring + sink <= 160 KiB: W <= 86
 }
 
-template <int BN, int WP, int WC>
+template <int BN, int WP, int WC, bool SINGLE = false>
 static int launch_b3_win(const ConvArgs &a, hipStream_t st) {
     const int np = b3_win_pieces(a);
-    size_t lds = (size_t)4 * np * 1024 + 3 * (size_t)2 * BN * 64 + 1024;
+    size_t lds = (size_t)(SINGLE ? 2 : 4) * np * 1024 + 3 * (size_t)2 * BN * 64 + 1024;
     if (lds < (size_t)256 * BN * 4) lds = (size_t)256 * BN * 4;   // the epilogue's accumulator tile
-    auto k = conv_b3_win_kernel<BN, WP, WC>;
+    auto k = conv_b3_win_kernel<BN, WP, WC, SINGLE>;
     if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, 1), dim3(WP * WC * 64), lds, st, a, np);
     CER_HIP_CHECK(hipGetLastError());
@@ -623,18 +664,18 @@ bool conv_b3_win_ok(const ConvArgs &a) {
 }
 
 int conv_b3_patch_launch(int tile, const ConvArgs &a, hipStream_t st) {
-    if (tile == 55 || tile == 56) {
+    if (tile == 56 || tile == 53) {
         if (!conv_b3_win_ok(a))
             return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3, window kernel): needs a 3x3 / stride 1 / pad 1 conv with W <= 86, "
                                                        "Cin % 32 == 0, no split-K");
-        return tile == 55 ? launch_b3_win<64, 4, 2>(a, st) : launch_b3_win<128, 4, 2>(a, st);
+        if (tile == 53) return launch_b3_win<64, 4, 1, true>(a, st);   // single-phase, one window buffer, two blocks per CU
+        return launch_b3_win<128, 4, 2>(a, st);
     }
     if (!conv_b3_patch_ok(a))
         return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3, patch kernel): needs a 3x3 / stride 1 / pad 1 conv on images whose "
                                                    "height and width are multiples of 16, Cin % 32 == 0, no split-K");
     switch (tile) {
         case 59: return launch_b3_patch<64, 4, 1, true>(a, st);      // single-phase, one window buffer, two blocks per CU
-        case 57: return launch_b3_patch<64, 4, 2>(a, st);
         case 58: return launch_b3_patch<128, 4, 2>(a, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3, patch kernel): unknown tile id");
     }

@@ -34,17 +34,20 @@ def test_split_is_round_to_nearest_and_exact_to_16_bits():
     (3, 64, 64, 12, 3, 1, 48), (3, 64, 40, 7, 3, 1, 48), (5, 128, 64, 9, 3, 2, 48), (4, 64, 64, 9, 1, 2, 48),
     # patch kernels (input window of a 16x16 output patch resident in LDS, ping-pong phases): borders on every side, several
     # patches per image, ragged Cout, 1 / 2 / 4 / 8 channel chunks of 32, two cout tiles per patch
-    (2, 64, 64, 32, 3, 1, 57), (1, 64, 128, 48, 3, 1, 57), (2, 32, 40, 16, 3, 1, 57), (3, 128, 64, 16, 3, 1, 57),
+    (2, 64, 64, 32, 3, 1, 59), (1, 64, 128, 48, 3, 1, 59), (2, 32, 40, 16, 3, 1, 59), (3, 128, 64, 16, 3, 1, 59),
     (2, 128, 128, 32, 3, 1, 58), (1, 128, 256, 32, 3, 1, 58), (1, 256, 128, 16, 3, 1, 58), (3, 64, 100, 32, 3, 1, 58),
     # 4 waves, one window buffer re-filled per chunk, two blocks per CU
-    (2, 64, 64, 32, 3, 1, 59), (1, 64, 128, 48, 3, 1, 59), (2, 32, 40, 16, 3, 1, 59), (3, 128, 64, 16, 3, 1, 59), (1, 256, 64, 16, 3, 1, 59),
+    (1, 256, 64, 16, 3, 1, 59),
     # 1-D window kernels (any image size; 256 consecutive pixels span image rows and images): the reference's 40x40 crop
     # pyramid (40 / 20 / 10 / 5), the 224x224 pyramid's 56 / 28 / 14 / 7, tiny images (many per tile), ragged M and Cout,
     # the widest image the LDS takes (86)
-    (3, 64, 64, 40, 3, 1, 55), (2, 64, 128, 20, 3, 1, 55), (5, 128, 40, 10, 3, 1, 55), (7, 64, 64, 5, 3, 1, 55),
-    (1, 32, 64, 56, 3, 1, 55), (50, 64, 64, 2, 3, 1, 55), (3, 64, 64, 3, 3, 1, 55),
+    (3, 64, 64, 40, 3, 1, 53), (2, 64, 128, 20, 3, 1, 53), (5, 128, 40, 10, 3, 1, 53), (7, 64, 64, 5, 3, 1, 53),
+    (1, 32, 64, 56, 3, 1, 53), (50, 64, 64, 2, 3, 1, 53), (3, 64, 64, 3, 3, 1, 53),
     (2, 128, 128, 56, 3, 1, 56), (3, 256, 256, 28, 3, 1, 56), (5, 128, 200, 14, 3, 1, 56), (9, 512, 512, 7, 3, 1, 56),
-    (2, 64, 128, 40, 3, 1, 56), (1, 64, 128, 86, 3, 1, 56), (1, 32, 128, 17, 3, 1, 56)])
+    (2, 64, 128, 40, 3, 1, 56), (1, 64, 128, 86, 3, 1, 56), (1, 32, 128, 17, 3, 1, 56),
+    # 1-D window, 4 waves, one window buffer re-filled per chunk (two blocks per CU)
+    (1, 64, 128, 86, 3, 1, 53),
+    (9, 256, 64, 7, 3, 1, 53)])
 def test_conv_b3_matches_fp32(n, cin, cout, hw, k, stride, tile):
     from feature_vs_text_compound_emotion_amd import ops
     x, w = _setup(n, cin, cout, hw, k, n * 100 + cin + cout)
@@ -87,14 +90,14 @@ def test_conv_b3_fused_epilogue_outputs(tile):
     assert (st[1] - (raw * raw).sum((0, 2, 3))).abs().max().item() < 1e-2
 
 
-@pytest.mark.parametrize("cin,cout,tile", [(64, 64, 57), (64, 128, 58), (128, 200, 58), (64, 64, 59), (64, 64, 0), (128, 128, 0),
-                                           (64, 64, 55), (64, 128, 56), (128, 200, 56)])
+@pytest.mark.parametrize("cin,cout,tile", [(64, 64, 59), (64, 128, 58), (128, 200, 58), (64, 64, 0), (128, 128, 0),
+                                           (64, 64, 53), (64, 128, 56), (128, 200, 56)])
 def test_conv_b3_patch_kernel_epilogue_on_non_square_images(cin, cout, tile):
     """bf16x3 patch kernels: H != W, bias9 (folded input BatchNorm) + PReLU + split residual + statistics; tile 0 on a shape
     the picker routes to them."""
     from feature_vs_text_compound_emotion_amd import ops
     g = torch.Generator().manual_seed(cin + cout)
-    n, h, w = (176, 32, 48) if tile == 0 else ((3, 13, 21) if tile in (55, 56) else (2, 32, 48))
+    n, h, w = (176, 32, 48) if tile == 0 else ((3, 13, 21) if tile in (53, 56) else (2, 32, 48))
     x = torch.randn(n, cin, h, w, generator=g)
     wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
     s1, t1 = torch.rand(cin, generator=g) + 0.5, torch.randn(cin, generator=g) * 0.5
@@ -114,7 +117,7 @@ def test_conv_b3_patch_kernel_epilogue_on_non_square_images(cin, cout, tile):
     assert (st[0] - raw.sum((0, 2, 3))).abs().max().item() < 2e-6 * npix + 1e-2
     assert (st[1] - (raw * raw).sum((0, 2, 3))).abs().max().item() < 2e-6 * npix + 1e-2
     if tile != 0:
-        with pytest.raises(RuntimeError, match="window" if tile in (55, 56) else "patch"):
+        with pytest.raises(RuntimeError, match="window" if tile in (53, 56) else "patch"):
             ops.conv2d_b3(xs, wp, 3, 3, stride=2, pad=(1, 1), tile=tile)
 
 
@@ -168,7 +171,7 @@ def test_bn_apply_split_io():
     assert (st[0] - ref.sum((0, 1, 2))).abs().max().item() < 1e-2
 
 
-@pytest.mark.parametrize("tile,hw", [(56, 14), (58, 16), (41, 9), (55, 10), (57, 16)])
+@pytest.mark.parametrize("tile,hw", [(56, 14), (58, 16), (41, 9), (53, 10), (59, 16)])
 @pytest.mark.parametrize("kind", ["raw_f32", "b9_prelu_split", "bias_res_split"])
 def test_specialised_row_epilogues_on_every_kernel_family(kind, tile, hw):
     """The straight-line row epilogues (conv_common.h: epi_mode / epi_row) are selected by the EXACT combination of outputs a
@@ -176,7 +179,7 @@ def test_specialised_row_epilogues_on_every_kernel_family(kind, tile, hw):
     raw conv result -> fp32 (+ statistics); border bias (folded input BatchNorm) + PReLU -> split; bias + same-geometry split
     residual -> split."""
     from feature_vs_text_compound_emotion_amd import ops
-    cin, cout = 64, (64 if tile in (55, 57) else 128)
+    cin, cout = 64, (64 if tile in (53, 59) else 128)
     n = 5
     g = torch.Generator().manual_seed(tile * 10 + len(kind))
     x = torch.randn(n, cin, hw, hw, generator=g)
