@@ -38,6 +38,7 @@ NARROW = ("bf16", "fp16")
 KERNEL_NAMES = {41: "cer::conv_b3_dma16_kernel<128, 128, 2, 2, 4, 2>", 42: "cer::conv_b3_dma16_kernel<128, 64, 2, 2, 4, 2>",
                 44: "cer::conv_b3_dma16_kernel<64, 128, 1, 4, 4, 2>", 45: "cer::conv_b3_dma16_kernel<64, 64, 2, 2, 4, 2>",
                 48: "cer::conv_b3_dma16_kernel<256, 64, 4, 1, 4, 2>",
+                51: "cer::conv_b3_s2d_kernel<64>", 52: "cer::conv_b3_s2d_kernel<128>",
                 53: "cer::conv_b3_win_kernel<64, 4, 1, true>", 56: "cer::conv_b3_win_kernel<128, 4, 2, false>",
                 58: "cer::conv_b3_patch_kernel<128, 4, 2, false>", 59: "cer::conv_b3_patch_kernel<64, 4, 1, true>",
                 71: "cer::conv_n16_patch_kernel<64, 4, 1, 1, {f16}, false>", 72: "cer::conv_n16_patch_kernel<128, 4, 2, 2, {f16}, false>",
@@ -84,7 +85,7 @@ def kernel_source_sha():
     """Identity of the code the traffic profiles were taken on: the conv / BatchNorm kernel sources."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "feature_vs_text_compound_emotion_amd", "csrc")
-    for f in ("conv_common.h", "conv_b3.hip", "conv_b3_patch.hip", "conv_n16.hip", "conv_n16_patch.hip", "conv_igemm.hip", "encoder_bn.hip"):
+    for f in ("conv_common.h", "conv_b3.hip", "conv_b3_patch.hip", "conv_b3_s2d.hip", "conv_n16.hip", "conv_n16_patch.hip", "conv_igemm.hip", "encoder_bn.hip"):
         with open(os.path.join(csrc, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

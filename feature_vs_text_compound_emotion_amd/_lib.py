@@ -20,7 +20,8 @@ class ConvDesc(Structure):
         "N", "H", "W", "Cin", "Ho", "Wo", "Cout", "KH", "KW", "stride", "dil_h", "dil_w", "pad_t", "pad_l",
         "x_nchw", "res_stride", "Hr", "Wr", "act1", "act2")] + [("slope", c_float), ("split_k", c_int32),
                                                                 ("tile", c_int32), ("x_ld", c_int32),
-                                                                ("y_ld", c_int32), ("storage", c_int32)]
+                                                                ("y_ld", c_int32), ("storage", c_int32),
+                                                                ("x_s2d", c_int32), ("y_s2d", c_int32)]
 
 
 _P = c_void_p
@@ -38,6 +39,7 @@ _SIGNATURES = {
     "cer_last_error": (c_char_p, []),
     "cer_version": (c_int, []),
     "cer_conv_kpad": (c_int, [c_int, c_int, c_int]),
+    "cer_conv_s2d_k_order": (c_int, [c_int, POINTER(c_int32)]),
     "cer_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "cer_conv2d_stats_tiles": (c_int, [POINTER(ConvDesc), c_int]),
     "cer_conv2d_run": (c_int, [POINTER(ConvDesc), POINTER(ConvIO), _P, c_size_t, _P]),

@@ -18,5 +18,7 @@ __device__ __forceinline__ int swz16(int q) { return (0x78 >> (2 * q)) & 3; }  /
 int conv_b3_patch_launch(int tile, const ConvArgs &a, hipStream_t st);  // conv_b3_patch.hip
 bool conv_b3_patch_ok(const ConvArgs &a);
 bool conv_b3_win_ok(const ConvArgs &a);
+int conv_b3_s2d_launch(int tile, const ConvArgs &a, hipStream_t st);    // conv_b3_s2d.hip
+bool conv_b3_s2d_ok(const ConvArgs &a);
 
 }  // namespace cer

@@ -393,6 +393,12 @@ int conv_b3_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
     int tile = d->tile;
     const long long M = (long long)d->N * d->Ho * d->Wo;
     const int Cout = d->Cout;
+    if (d->x_s2d) {   // space-to-depth input: only the window-resident stride-2 kernel reads it (conv_b3_s2d.hip)
+        if (tile == 0) tile = Cout > 64 ? 52 : 51;
+        else if (tile != 51 && tile != 52) return 0;
+    } else if (tile == 51 || tile == 52) {
+        return 0;
+    }
     if (tile == 0) {
         // measured per layer shape on MI355X (tools/bench_conv.py)
         const long long t128 = (M + 127) / 128 * ((Cout + 127) / 128), t256 = (M + 255) / 256;
@@ -415,6 +421,8 @@ int conv_b3_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         case 58: bm = 256; bn = 128; break;
         case 53: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels (53: 4 waves, one window)
         case 56: bm = 256; bn = 128; break;
+        case 51: bm = 256; bn = 64; break;    // 3x3 / stride 2 on a space-to-depth input (conv_b3_s2d.hip)
+        case 52: bm = 256; bn = 128; break;
         default: return 0;
     }
     return tile;
@@ -428,6 +436,7 @@ int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 45: return launch_b3_dma16<64, 64, 2, 2>(a, st);
         case 48: return launch_b3_dma16<256, 64, 4, 1>(a, st);
         case 53: case 56: case 58: case 59: return conv_b3_patch_launch(tile, a, st);
+        case 51: case 52: return conv_b3_s2d_launch(tile, a, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3): unknown tile id");
     }
 }

@@ -34,7 +34,17 @@ struct ConvArgs {
     // narrow storage (cer_conv_desc.storage): 0 = fp32 / split tensors as the pointers say; CER_STORE_BF16 / CER_STORE_F16 =
     // every 16-bit tensor of the launch (x_hi, w_hi, res_hi, y_hi) is ONE plane of that type and the *_lo pointers are NULL
     int narrow;
+    // cer_conv_desc.y_s2d: the 16-bit output planes are written space-to-depth (row permutation s2d_row() of the stores);
+    // x_s2d: the input is such a tensor (x_ld = 4 Cin), conv_b3_s2d.hip
+    int y_s2d, x_s2d;
 };
+
+// Row of output pixel m = (n, ho, wo) in the space-to-depth view [N * Ho/2 * Wo/2 * 4][C] of an [N, Ho, Wo, C] tensor:
+// 4 * ((n * Ho/2 + ho/2) * Wo/2 + wo/2) + blk with blk = 3 - 2 (ho & 1) - (wo & 1) (block order P11 | P10 | P01 | P00, the
+// order conv_b3_s2d_kernel walks the phases in).  Ho and Wo are even.
+__host__ __device__ __forceinline__ int s2d_row(int m, int ho, int wo, int Wo) {
+    return (m - ho * Wo - wo) + 4 * ((ho >> 1) * (Wo >> 1) + (wo >> 1)) + 3 - 2 * (ho & 1) - (wo & 1);
+}
 
 template <int I> struct IdxC { static constexpr int v = I; };
 template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {

@@ -519,7 +519,15 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
     a.narrow = d->storage;
     if (io->bias9 && (io->bias || d->stride != 1 || d->Ho != d->H || d->Wo != d->W || d->H < 2 || d->W < 2 || d->split_k > 1))
         return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: bias9 replaces bias and needs a stride-1 same conv on >= 2x2 images without split-K");
-    a.x_ld = d->x_ld > 0 ? d->x_ld : d->Cin;
+    if (d->x_s2d || d->y_s2d) {
+        if (!b3) return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d: space-to-depth tensors exist in bf16x3 mode only");
+        if (d->x_s2d && d->x_ld > 0) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: x_s2d fixes the input pitch (x_ld must be 0)");
+        if (d->y_s2d && ((d->Ho | d->Wo) & 1 || io->y || io->y2_hi || has_res || io->mask || io->aux || d->y_ld > 0 || !io->y_hi))
+            return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: y_s2d needs even Ho / Wo and a plain 16-bit output (no fp32 / second "
+                                                      "output, residual, mask, aux or y_ld)");
+    }
+    a.x_s2d = d->x_s2d != 0; a.y_s2d = d->y_s2d != 0;
+    a.x_ld = d->x_s2d ? 4 * d->Cin : (d->x_ld > 0 ? d->x_ld : d->Cin);
     a.y_ld = d->y_ld > 0 ? d->y_ld : d->Cout;
     if (a.x_ld < d->Cin || a.y_ld < d->Cout || ((d->Cin % 32) == 0 && (a.x_ld & 3) != 0))
         return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: x_ld/y_ld smaller than the channel count or x_ld % 4 != 0");
@@ -541,7 +549,10 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
         esz = 2;
     } else if (b3) {
         tile = conv_b3_tile_dims(d, bm, bn, bk);
-        if (!tile) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3): unknown tile id");
+        if (!tile) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (bf16x3): unknown tile id (space-to-depth input: 51 / 52 only)");
+        if (d->y_s2d && tile != 53 && tile != 56 && tile != 58 && tile != 59)
+            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3): y_s2d is written by the window / patch kernels only "
+                                                      "(cer_conv2d_b3_tile(desc) in {53, 56, 58, 59})");
         if (d->Cin % bk != 0 || (a.x_ld & 7))
             return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (bf16x3): Cin must be a multiple of the K step and x_ld of 8");
         esz = 2;

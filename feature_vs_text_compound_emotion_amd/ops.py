@@ -193,16 +193,23 @@ CONV_TRACE = None
 
 def conv2d_b3(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bias=None, alpha=None, residual=None,
               res_stride=1, act1=ACT_NONE, act2=ACT_NONE, slope=LEAKY_SLOPE, split_k=1, tile=0, out_f32=False,
-              out_split=True, next_affine=None, want_stats=False, bias9=None):
+              out_split=True, next_affine=None, want_stats=False, bias9=None, x_s2d=False, y_s2d=False):
     """bf16x3 convolution.  x, w: Split tensors (x NHWC [N,H,W,Cin], w [Cout,Kpad]); residual: Split
     or fp32 tensor.  Returns a dict with the requested outputs: 'y' (fp32), 'split' (Split), 'next'
-    (Split of out*s2+t2 when ``next_affine=(s2, t2)``), 'stats'."""
+    (Split of out*s2+t2 when ``next_affine=(s2, t2)``), 'stats'.
+    ``y_s2d``: the Split output is stored space-to-depth, [N, Ho/2, Wo/2, 4*Cout] (``space_to_depth`` is the torch
+    statement of the layout); ``x_s2d``: x is such a tensor (of the [N, 2*x.shape[1], 2*x.shape[2], x.shape[3]/4] input of
+    this 3x3 / stride 2 / pad 1 conv) and w went through ``pack_s2d_weight``."""
     lib = _lib.load()
     for t, n in ((x.hi, "x.hi"), (x.lo, "x.lo"), (w.hi, "w.hi"), (w.lo, "w.lo")):
         _dev_bf16(t, n)
     _dev_f32(bias, "bias")
     _dev_f32(alpha, "alpha")
     n, h, wd, cin = x.shape
+    if x_s2d:
+        if cin % 4:
+            raise ValueError("a space-to-depth input has 4 * Cin channels")
+        h, wd, cin = 2 * h, 2 * wd, cin // 4
     cout = w.shape[0]
     if w.shape[1] != conv_kpad(kh, kw, cin):
         raise ValueError(f"packed weight has K={w.shape[1]}, expected {conv_kpad(kh, kw, cin)}")
@@ -216,6 +223,7 @@ def conv2d_b3(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bi
     d.KH, d.KW, d.stride, d.dil_h, d.dil_w, d.pad_t, d.pad_l = kh, kw, stride, dil[0], dil[1], pad[0], pad[1]
     d.res_stride, d.Hr, d.Wr = res_stride, 0, 0
     d.act1, d.act2, d.slope, d.split_k, d.tile = act1, act2, slope, split_k, tile
+    d.x_s2d, d.y_s2d = int(x_s2d), int(y_s2d)
     io = ConvIO()
     io.x_hi, io.x_lo, io.w_hi, io.w_lo = x.hi.data_ptr(), x.lo.data_ptr(), w.hi.data_ptr(), w.lo.data_ptr()
     io.bias = bias.data_ptr() if bias is not None else None
@@ -242,7 +250,7 @@ def conv2d_b3(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bi
         res["y"] = torch.empty((n, ho, wo, cout), device=dev, dtype=torch.float32)
         io.y = res["y"].data_ptr()
     if out_split:
-        res["split"] = Split.empty((n, ho, wo, cout), dev)
+        res["split"] = Split.empty((n, ho // 2, wo // 2, 4 * cout) if y_s2d else (n, ho, wo, cout), dev)
         io.y_hi, io.y_lo = res["split"].hi.data_ptr(), res["split"].lo.data_ptr()
     if next_affine is not None:
         s2, t2 = next_affine
@@ -269,6 +277,43 @@ def conv2d_b3(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bi
             4.0 * cout * cin * kh * kw + (4.0 * nout if residual is not None else 0.0)
         CONV_TRACE.append((lib.cer_conv2d_b3_tile(ctypes.byref(d)), 2.0 * n * ho * wo * cout * cin * kh * kw, e0, e1, nbytes))
     return res
+
+
+def conv2d_b3_tile(n, h, w, cin, cout, kh, kw, stride, pad, x_s2d=False):
+    """The bf16x3 kernel variant ``conv2d_b3`` would launch for this conv (cer_conv2d_b3_tile)."""
+    d = ConvDesc()
+    d.N, d.H, d.W, d.Cin, d.Cout = n, h, w, cin, cout
+    d.Ho, d.Wo = (h + 2 * pad[0] - kh) // stride + 1, (w + 2 * pad[1] - kw) // stride + 1
+    d.KH, d.KW, d.stride, d.dil_h, d.dil_w, d.pad_t, d.pad_l = kh, kw, stride, 1, 1, pad[0], pad[1]
+    d.split_k, d.x_s2d = 1, int(x_s2d)
+    return _lib.load().cer_conv2d_b3_tile(ctypes.byref(d))
+
+
+S2D_PRODUCER_TILES = (53, 56, 58, 59)   # the window / patch kernels: their epilogues can store space-to-depth
+
+
+def s2d_k_order(cin, device):
+    """K-column order of an ``x_s2d`` conv's weights (cer_conv_s2d_k_order) as an index tensor."""
+    order = (ctypes.c_int32 * (9 * cin))()
+    check(_lib.load().cer_conv_s2d_k_order(cin, order), "cer_conv_s2d_k_order")
+    return torch.tensor(list(order), dtype=torch.long, device=device)
+
+
+def pack_s2d_weight(w, cin):
+    """Packed 3x3 weights [Cout, 9*Cin] (fp32 tensor, Split or narrow plane) -> the same columns in the step order of the
+    space-to-depth stride-2 kernel."""
+    idx = s2d_k_order(cin, (w.hi if isinstance(w, Split) else w).device)
+    if isinstance(w, Split):
+        return Split(w.hi.index_select(1, idx).contiguous(), w.lo.index_select(1, idx).contiguous())
+    return w.index_select(1, idx).contiguous()
+
+
+def space_to_depth(x):
+    """[N, H, W, C] -> [N, H/2, W/2, 4C] with channel blocks ordered P11 | P10 | P01 | P00 (block = 3 - 2*(row & 1) - (col & 1)):
+    the torch statement of the layout ``y_s2d`` stores and ``x_s2d`` reads (tests; the product path never makes this copy)."""
+    if isinstance(x, Split):
+        return Split(space_to_depth(x.hi), space_to_depth(x.lo))
+    return torch.cat([x[:, 1::2, 1::2], x[:, 1::2, 0::2], x[:, 0::2, 1::2], x[:, 0::2, 0::2]], dim=3).contiguous()
 
 
 # ------------------------------------------------------------------ narrow storage (one bf16 / half plane per tensor)

@@ -377,6 +377,8 @@ class IR50(nn.Module):
             d["a1"] = u.res_layer[2].weight.detach().contiguous()
             s2, b2 = self._bn_affine(u.res_layer[4])
             d["w2"] = ops.split_bf16(ops.pack_conv_weight(u.res_layer[3].weight.detach().contiguous(), s2))
+            if u.stride == 2 and u.depth % 64 == 0:   # the same columns in the space-to-depth kernel's step order
+                d["w2_s2d"] = ops.pack_s2d_weight(d["w2"], u.depth)
             d["b2"] = b2
             if d["proj"]:
                 ss, sb = self._bn_affine(u.shortcut_layer[1])
@@ -406,6 +408,8 @@ class IR50(nn.Module):
         for u in self.body:
             d = {"w1_f32": ops.pack_conv_weight(u.res_layer[1].weight.detach().contiguous()),  # folded per step (batch statistics)
                  "w2": ops.split_bf16(ops.pack_conv_weight(u.res_layer[3].weight.detach().contiguous()))}
+            if u.stride == 2 and u.depth % 64 == 0:
+                d["w2_s2d"] = ops.pack_s2d_weight(d["w2"], u.depth)
             if u.cin != u.depth:
                 d["ws"] = ops.split_bf16(ops.pack_conv_weight(u.shortcut_layer[0].weight.detach().contiguous()))
             P["units"].append(d)
@@ -568,6 +572,20 @@ class IR50(nn.Module):
                              if isinstance(m, (nn.BatchNorm2d, nn.BatchNorm1d))], 1)
         return ops.l2norm_rows(e)
 
+    _S2D_OK = {}
+
+    @classmethod
+    def _s2d_pair_ok(cls, xshape, depth):
+        """Can the two 3x3 convs of a stride-2 unit hand their intermediate over space-to-depth?  The first conv (xshape ->
+        depth, stride 1) has to run on a window / patch kernel (their epilogues can permute the stores) and the second one
+        needs even H and W, depth % 64 == 0 and Wo <= 126 (csrc/conv_b3_s2d.hip); otherwise the flat stride-2 kernel runs."""
+        key = (xshape, depth)
+        if key not in cls._S2D_OK:
+            n, h, w, cin = xshape
+            cls._S2D_OK[key] = h % 2 == 0 and w % 2 == 0 and depth % 64 == 0 and w // 2 <= 126 and cin % 32 == 0 and \
+                ops.conv2d_b3_tile(n, h, w, cin, depth, 3, 3, 1, (1, 1)) in ops.S2D_PRODUCER_TILES
+        return cls._S2D_OK[key]
+
     def _forward_b3(self, x):
         """Eval / frozen forward on the bf16x3 kernels (Cin = 3 stem on the fp32 small-Cin kernel)."""
         P = self.pack_b3()
@@ -576,12 +594,14 @@ class IR50(nn.Module):
                         act1=ops.ACT_PRELU, x_nchw=True, want_f32=False, out_split=True)["split"]
         for d in U:
             s = d["stride"]
-            t = ops.conv2d_b3(xs, d["w1"], 3, 3, pad=(1, 1), bias9=d["b9"], alpha=d["a1"], act1=ops.ACT_PRELU)["split"]
+            s2d = "w2_s2d" in d and self._s2d_pair_ok(tuple(xs.shape), d["w2"].shape[0])
+            t = ops.conv2d_b3(xs, d["w1"], 3, 3, pad=(1, 1), bias9=d["b9"], alpha=d["a1"], act1=ops.ACT_PRELU, y_s2d=s2d)["split"]
+            w2 = d["w2_s2d"] if s2d else d["w2"]
             if d["proj"]:
                 sc = ops.conv2d_b3(xs, d["ws"], 1, 1, stride=s, bias=d["bs"])["split"]
-                xs = ops.conv2d_b3(t, d["w2"], 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=sc, res_stride=1)["split"]
+                xs = ops.conv2d_b3(t, w2, 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=sc, res_stride=1, x_s2d=s2d)["split"]
             else:
-                xs = ops.conv2d_b3(t, d["w2"], 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=xs, res_stride=s)["split"]
+                xs = ops.conv2d_b3(t, w2, 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=xs, res_stride=s, x_s2d=s2d)["split"]
         n, h, w, c = xs.shape
         if h != self.head_hw or w != self.head_hw:
             raise RuntimeError(f"IR50 head was built for {self.head_hw}x{self.head_hw} feature maps "
@@ -620,10 +640,11 @@ class IR50(nn.Module):
             last = i + 1 == first_released  # the next consumer (released unit or head) wants fp32
             s1, t1 = self._finalize(xst, ys.hi.numel() // u.cin, u.res_layer[0])
             w1, b9 = ops.fold_bn_3x3_packed(d["w1_f32"], s1, t1, "split")
+            s2d = "w2_s2d" in d and self._s2d_pair_ok(tuple(ys.shape), u.depth)
             tt = ops.conv2d_b3(ys, w1, 3, 3, pad=(1, 1), alpha=u.res_layer[2].weight.detach(),
-                               act1=ops.ACT_PRELU, bias9=b9)["split"]
-            r = ops.conv2d_b3(tt, d["w2"], 3, 3, stride=u.stride, pad=(1, 1), out_f32=True, out_split=False,
-                              want_stats=True)
+                               act1=ops.ACT_PRELU, bias9=b9, y_s2d=s2d)["split"]
+            r = ops.conv2d_b3(tt, d["w2_s2d"] if s2d else d["w2"], 3, 3, stride=u.stride, pad=(1, 1), out_f32=True,
+                              out_split=False, want_stats=True, x_s2d=s2d)
             del tt
             z = r["y"]
             cnt = z.numel() // u.depth

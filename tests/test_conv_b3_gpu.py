@@ -213,3 +213,74 @@ def test_specialised_row_epilogues_on_every_kernel_family(kind, tile, hw):
         got = r["split"].float().cpu().permute(0, 3, 1, 2).double()
         tol = tol + 2.0 ** -14 * (ref.abs() + res.double().abs())   # split residual in, split result out
     assert ((got - ref).abs() <= tol).all(), ((got - ref).abs() / tol).max().item()
+
+
+# ---- space-to-depth hand-over of the stride-2 units: producer layout, then the window-resident stride-2 kernel ----
+@pytest.mark.parametrize("n,cin,cout,h,w,tile", [(2, 64, 64, 32, 48, 59), (1, 64, 128, 16, 32, 58), (3, 64, 128, 20, 12, 56),
+                                                 (5, 128, 40, 10, 6, 53), (12, 64, 64, 40, 40, 0)])
+def test_producer_writes_the_space_to_depth_layout(n, cin, cout, h, w, tile):
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(n + cin + h)
+    x = torch.randn(n, h, w, cin, generator=g).cuda()
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    b9, alpha = torch.randn(9, cout, generator=g).cuda(), (torch.rand(cout, generator=g) * 0.3 + 0.1).cuda()
+    xs, ws = ops.split_bf16(x), ops.split_bf16(ops.pack_conv_weight(wt.cuda()))
+    kw = dict(pad=(1, 1), bias9=b9, alpha=alpha, act1=ops.ACT_PRELU, tile=tile)
+    plain = ops.conv2d_b3(xs, ws, 3, 3, **kw)["split"]
+    s2d = ops.conv2d_b3(xs, ws, 3, 3, y_s2d=True, **kw)["split"]
+    assert tuple(s2d.shape) == (n, h // 2, w // 2, 4 * cout)
+    want = ops.space_to_depth(plain)
+    assert torch.equal(s2d.hi, want.hi) and torch.equal(s2d.lo, want.lo)     # the same values, the stores permuted
+    # and without a bias9 (the generic epilogue)
+    plain = ops.conv2d_b3(xs, ws, 3, 3, pad=(1, 1), tile=tile)["split"]
+    s2d = ops.conv2d_b3(xs, ws, 3, 3, pad=(1, 1), tile=tile, y_s2d=True)["split"]
+    assert torch.equal(s2d.hi, ops.space_to_depth(plain.hi)) and torch.equal(s2d.lo, ops.space_to_depth(plain.lo))
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [
+    (3, 64, 64, 16, 16), (2, 64, 128, 40, 40), (2, 128, 128, 20, 20), (1, 256, 200, 12, 10), (7, 512, 512, 10, 10),
+    (1, 64, 64, 224, 224), (2, 128, 128, 112, 112), (1, 64, 40, 4, 252), (5, 128, 256, 6, 2), (9, 64, 64, 2, 2), (1, 64, 128, 34, 30)])
+def test_stride2_conv_on_a_space_to_depth_input(n, cin, cout, h, w):
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(n * 7 + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5
+    ref = F.conv2d(x.double(), wt.double(), None, 2, 1)
+    mag = F.conv2d(x.double().abs(), wt.double().abs(), None, 2, 1)
+    bound = mag * (2.0 ** -15 + cin * 9 * 2.0 ** -24) + 1e-7
+    xs = ops.split_bf16(x.permute(0, 2, 3, 1).contiguous().cuda())
+    ws = ops.split_bf16(ops.pack_conv_weight(wt.cuda()))
+    r = ops.conv2d_b3(ops.space_to_depth(xs), ops.pack_s2d_weight(ws, cin), 3, 3, stride=2, pad=(1, 1), x_s2d=True,
+                      out_f32=True, out_split=False, want_stats=True)
+    got = r["y"].cpu().permute(0, 3, 1, 2).double()
+    assert tuple(got.shape) == tuple(ref.shape)
+    assert ((got - ref).abs() <= bound).all(), ((got - ref).abs() / bound).max().item()
+    flat = ops.conv2d_b3(xs, ws, 3, 3, stride=2, pad=(1, 1), out_f32=True, out_split=False)["y"]
+    assert (flat - r["y"]).abs().max().item() < 2e-5            # the flat kernel: same products, another summation order
+    st = r["stats"].double().cpu().sum(0)
+    assert (st[0] - ref.sum((0, 2, 3))).abs().max().item() < 1e-2 * max(1.0, (n * h * w / 400) ** 0.5)
+    assert (st[1] - (ref * ref).sum((0, 2, 3))).abs().max().item() < 1e-2 * max(1.0, n * h * w / 400)
+
+
+def test_stride2_space_to_depth_conv_with_the_eval_epilogue_and_its_errors():
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(11)
+    n, cin, cout, h, w = 2, 64, 128, 20, 12
+    x, wt = torch.randn(n, cin, h, w, generator=g), torch.randn(cout, cin, 3, 3, generator=g) / 24.0
+    bias, res = torch.randn(cout, generator=g), torch.randn(n, cout, h, w, generator=g)
+    z = F.conv2d(x, wt, None, 2, 1) + bias.view(1, -1, 1, 1) + res[:, :, ::2, ::2]
+    xs = ops.space_to_depth(ops.split_bf16(x.permute(0, 2, 3, 1).contiguous().cuda()))
+    ws = ops.pack_s2d_weight(ops.split_bf16(ops.pack_conv_weight(wt.cuda())), cin)
+    rs = ops.split_bf16(res.permute(0, 2, 3, 1).contiguous().cuda())
+    r = ops.conv2d_b3(xs, ws, 3, 3, stride=2, pad=(1, 1), x_s2d=True, bias=bias.cuda(), residual=rs, res_stride=2)["split"]
+    assert (r.float().cpu().permute(0, 3, 1, 2) - z).abs().max().item() < 1e-4
+    with pytest.raises(RuntimeError, match="space-to-depth"):      # a flat tile cannot read the layout
+        ops.conv2d_b3(xs, ws, 3, 3, stride=2, pad=(1, 1), x_s2d=True, tile=41)
+    x96 = ops.Split(xs.hi[..., :4 * 32].contiguous(), xs.lo[..., :4 * 32].contiguous())
+    w96 = ops.Split(ws.hi[:, :9 * 32].contiguous(), ws.lo[:, :9 * 32].contiguous())
+    with pytest.raises(RuntimeError, match="Cin % 64"):
+        ops.conv2d_b3(x96, w96, 3, 3, stride=2, pad=(1, 1), x_s2d=True)
+    plain = ops.split_bf16(x.permute(0, 2, 3, 1).contiguous().cuda())
+    w1 = ops.split_bf16(ops.pack_conv_weight(torch.randn(cout, cin, 3, 3, generator=g).cuda()))
+    with pytest.raises(RuntimeError, match="y_s2d"):               # flat tiles do not write it either
+        ops.conv2d_b3(plain, w1, 3, 3, pad=(1, 1), y_s2d=True, tile=41)
