@@ -45,6 +45,7 @@ KERNEL_NAMES = {41: "cer::conv_b3_dma16_kernel<128, 128, 2, 2, 4, 2>", 42: "cer:
                 78: "cer::conv_n16_patch_kernel<128, 4, 2, 2, {f16}, true>",
                 73: "cer::conv_n16_win_kernel<64, 4, 2, {f16}, false, 2>", 76: "cer::conv_n16_win_kernel<128, 4, 2, {f16}, true, 2>",
                 77: "cer::conv_n16_win_kernel<64, 4, 1, {f16}, false, 1>",
+                81: "cer::conv_n16_s2d_kernel<64, {f16}>", 82: "cer::conv_n16_s2d_kernel<128, {f16}>",
                 91: "cer::conv_n16_kernel<256, 256, 2, 4, {f16}, 2>", 94: "cer::conv_n16_kernel<128, 128, 2, 2, {f16}, 2>",
                 63: "cer::conv_n16_kernel<256, 64, 4, 1, {f16}, 1>", 64: "cer::conv_n16_kernel<128, 128, 2, 2, {f16}, 1>",
                 65: "cer::conv_n16_kernel<128, 64, 2, 2, {f16}, 1>", 66: "cer::conv_n16_kernel<64, 64, 2, 2, {f16}, 1>",
@@ -85,7 +86,7 @@ def kernel_source_sha():
     """Identity of the code the traffic profiles were taken on: the conv / BatchNorm kernel sources."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "feature_vs_text_compound_emotion_amd", "csrc")
-    for f in ("conv_common.h", "conv_b3.hip", "conv_b3_patch.hip", "conv_b3_s2d.hip", "conv_n16.hip", "conv_n16_patch.hip", "conv_igemm.hip", "encoder_bn.hip"):
+    for f in ("conv_common.h", "conv_b3.hip", "conv_b3_patch.hip", "conv_b3_s2d.hip", "conv_n16.hip", "conv_n16_s2d.hip", "conv_n16_patch.hip", "conv_igemm.hip", "encoder_bn.hip"):
         with open(os.path.join(csrc, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]

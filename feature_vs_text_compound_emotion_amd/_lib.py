@@ -39,7 +39,7 @@ _SIGNATURES = {
     "cer_last_error": (c_char_p, []),
     "cer_version": (c_int, []),
     "cer_conv_kpad": (c_int, [c_int, c_int, c_int]),
-    "cer_conv_s2d_k_order": (c_int, [c_int, POINTER(c_int32)]),
+    "cer_conv_s2d_k_order": (c_int, [c_int, c_int, POINTER(c_int32)]),
     "cer_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "cer_conv2d_stats_tiles": (c_int, [POINTER(ConvDesc), c_int]),
     "cer_conv2d_run": (c_int, [POINTER(ConvDesc), POINTER(ConvIO), _P, c_size_t, _P]),

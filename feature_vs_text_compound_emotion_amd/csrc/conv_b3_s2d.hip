@@ -373,16 +373,17 @@ int conv_b3_s2d_launch(int tile, const ConvArgs &a, hipStream_t st) {
 
 }  // namespace cer
 
-// The K order conv_b3_s2d_kernel consumes its weight slices in: phase-major (P11, P10, P01, P00), then the 32-channel chunk,
-// then the phase's shifts; each step is 32 consecutive channels of one filter tap.
-extern "C" int cer_conv_s2d_k_order(int Cin, int32_t *order) {
-    if (!order || Cin <= 0 || (Cin & 63)) return cer_set_error(CER_ERR_INVALID_ARG, "conv_s2d_k_order: Cin must be a positive multiple of 64");
+// The K order the space-to-depth kernels consume their weight slices in: phase-major (P11, P10, P01, P00), then the channel
+// chunk (32 channels: bf16x3, 64: narrow), then the phase's shifts; each step is `chunk` consecutive channels of one filter tap.
+extern "C" int cer_conv_s2d_k_order(int Cin, int chunk, int32_t *order) {
+    if (!order || Cin <= 0 || (chunk != 32 && chunk != 64) || Cin % (2 * chunk))
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv_s2d_k_order: chunk is 32 or 64 and Cin a positive multiple of 2 * chunk");
     static const int taps[4][4] = {{0, 2, 6, 8}, {1, 7, -1, -1}, {3, 5, -1, -1}, {4, -1, -1, -1}};
     static const int ntap[4] = {4, 2, 2, 1};
     int j = 0;
     for (int ph = 0; ph < 4; ++ph)
-        for (int cc = 0; cc < Cin / 32; ++cc)
+        for (int cc = 0; cc < Cin / chunk; ++cc)
             for (int t = 0; t < ntap[ph]; ++t)
-                for (int c = 0; c < 32; ++c) order[j++] = taps[ph][t] * Cin + cc * 32 + c;
+                for (int c = 0; c < chunk; ++c) order[j++] = taps[ph][t] * Cin + cc * chunk + c;
     return CER_OK;
 }

@@ -520,7 +520,7 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
     if (io->bias9 && (io->bias || d->stride != 1 || d->Ho != d->H || d->Wo != d->W || d->H < 2 || d->W < 2 || d->split_k > 1))
         return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: bias9 replaces bias and needs a stride-1 same conv on >= 2x2 images without split-K");
     if (d->x_s2d || d->y_s2d) {
-        if (!b3) return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d: space-to-depth tensors exist in bf16x3 mode only");
+        if (!b3 && !n16) return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d: space-to-depth tensors exist in the bf16x3 and narrow modes only");
         if (d->x_s2d && d->x_ld > 0) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: x_s2d fixes the input pitch (x_ld must be 0)");
         if (d->y_s2d && ((d->Ho | d->Wo) & 1 || io->y || io->y2_hi || has_res || io->mask || io->aux || d->y_ld > 0 || !io->y_hi))
             return cer_set_error(CER_ERR_INVALID_ARG, "conv2d: y_s2d needs even Ho / Wo and a plain 16-bit output (no fp32 / second "
@@ -543,7 +543,10 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
     int tile, bm, bn, bk, esz;
     if (n16) {
         tile = conv_n16_tile_dims(d, bm, bn, bk);
-        if (!tile) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (narrow): unknown tile id");
+        if (!tile) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (narrow): unknown tile id (space-to-depth input: 81 / 82 only)");
+        if (d->y_s2d && tile != 71 && tile != 72 && tile != 78 && tile != 73 && tile != 76 && tile != 77)
+            return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow): y_s2d is written by the window / patch kernels only "
+                                                      "(cer_conv2d_n16_tile(desc) in {71, 72, 73, 76, 77, 78})");
         if (d->Cin % bk != 0 || (a.x_ld & 7))
             return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow): Cin must be a multiple of 64 and x_ld of 8");
         esz = 2;

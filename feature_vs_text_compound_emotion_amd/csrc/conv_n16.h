@@ -21,5 +21,7 @@ __device__ __forceinline__ n_f32x4 mfma_n16(const n_u32x4 a, const n_u32x4 b, co
 int conv_n16_patch_launch(int tile, const ConvArgs &a, hipStream_t st);  // conv_n16_patch.hip
 bool conv_n16_patch_ok(const ConvArgs &a, int tile);         // can the patch kernel `tile` take this conv?
 bool conv_n16_win_ok(const ConvArgs &a);                     // can the 1-D window kernels (tiles 73 / 74)?
+int conv_n16_s2d_launch(int tile, const ConvArgs &a, hipStream_t st);    // conv_n16_s2d.hip
+bool conv_n16_s2d_ok(const ConvArgs &a);
 
 }  // namespace cer

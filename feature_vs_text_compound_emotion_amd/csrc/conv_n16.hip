@@ -379,6 +379,12 @@ int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
     int tile = d->tile;
     const long long M = (long long)d->N * d->Ho * d->Wo;
     const int Cout = d->Cout;
+    if (d->x_s2d) {   // space-to-depth input: only the window-resident stride-2 kernel reads it (conv_n16_s2d.hip)
+        if (tile == 0) tile = Cout > 64 ? 82 : 81;
+        else if (tile != 81 && tile != 82) return 0;
+    } else if (tile == 81 || tile == 82) {
+        return 0;
+    }
     if (tile == 0) {
         const long long t256 = (M + 255) / 256;
         if (patch_geometry(d) && d->Cin == 64 && t256 * ((Cout + 63) / 64) >= 1024) tile = 71;
@@ -408,6 +414,8 @@ int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         case 72: case 78: bm = 256; bn = 128; break;   // (78: ping-pong phases)
         case 73: case 77: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels (77: Cin == 64, one window)
         case 76: bm = 256; bn = 128; break;   // (ping-pong phases)
+        case 81: bm = 256; bn = 64; break;    // 3x3 / stride 2 on a space-to-depth input (conv_n16_s2d.hip)
+        case 82: bm = 256; bn = 128; break;
         default: return 0;
     }
     return tile;
@@ -421,6 +429,7 @@ int conv_n16_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 66: return launch_n16<64, 64, 2, 2>(a, st);
         case 67: return launch_n16<64, 128, 1, 4>(a, st);
         case 71: case 72: case 73: case 76: case 77: case 78: return conv_n16_patch_launch(tile, a, st);
+        case 81: case 82: return conv_n16_s2d_launch(tile, a, st);
         case 91: return launch_n16<256, 256, 2, 4, 2>(a, st);
         case 94: return launch_n16<128, 128, 2, 2, 2>(a, st);
         default: return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (narrow): unknown tile id");

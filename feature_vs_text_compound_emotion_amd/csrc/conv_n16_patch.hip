@@ -266,7 +266,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
                 }
                 const int gy = py * PH + oy;
                 const int ry = gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1);
-                epi_row<decltype(MODE_)::v>(p, ec, m, c, v, 3 * ry + rx);
+                epi_row<decltype(MODE_)::v>(p, ec, p.y_s2d ? s2d_row(m, gy, gx, p.W) : m, c, v, 3 * ry + rx);
             }
         }
     });
@@ -534,7 +534,8 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
     });
     __syncthreads();
     int ho = 0, wo = 0;
-    if (p.bias9) {
+    const bool track = p.bias9 || p.y_s2d;   // the row loop needs the pixel's image coordinates
+    if (track) {
         const int mm = m0 + r0 < p.M ? m0 + r0 : 0;
         const int r = mm % (p.Ho * p.Wo);
         ho = r / p.Wo;
@@ -553,9 +554,9 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
                     s2[t] += v[t] * v[t];
                 }
                 const int ry = ho == 0 ? 0 : (ho == p.Ho - 1 ? 2 : 1), rx = wo == 0 ? 0 : (wo == p.Wo - 1 ? 2 : 1);
-                epi_row<decltype(MODE_)::v>(p, ec, m, c, v, 3 * ry + rx);
+                epi_row<decltype(MODE_)::v>(p, ec, p.y_s2d ? s2d_row(m, ho, wo, p.Wo) : m, c, v, 3 * ry + rx);
             }
-            if (p.bias9) {
+            if (track) {
                 wo += RPI;
                 while (wo >= p.Wo) {
                     wo -= p.Wo;

@@ -279,33 +279,45 @@ def conv2d_b3(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bi
     return res
 
 
-def conv2d_b3_tile(n, h, w, cin, cout, kh, kw, stride, pad, x_s2d=False):
-    """The bf16x3 kernel variant ``conv2d_b3`` would launch for this conv (cer_conv2d_b3_tile)."""
+def _tile_desc(n, h, w, cin, cout, kh, kw, stride, pad, x_s2d):
     d = ConvDesc()
     d.N, d.H, d.W, d.Cin, d.Cout = n, h, w, cin, cout
     d.Ho, d.Wo = (h + 2 * pad[0] - kh) // stride + 1, (w + 2 * pad[1] - kw) // stride + 1
     d.KH, d.KW, d.stride, d.dil_h, d.dil_w, d.pad_t, d.pad_l = kh, kw, stride, 1, 1, pad[0], pad[1]
     d.split_k, d.x_s2d = 1, int(x_s2d)
-    return _lib.load().cer_conv2d_b3_tile(ctypes.byref(d))
+    return d
 
 
-S2D_PRODUCER_TILES = (53, 56, 58, 59)   # the window / patch kernels: their epilogues can store space-to-depth
+def conv2d_b3_tile(n, h, w, cin, cout, kh, kw, stride, pad, x_s2d=False):
+    """The bf16x3 kernel variant ``conv2d_b3`` would launch for this conv (cer_conv2d_b3_tile)."""
+    return _lib.load().cer_conv2d_b3_tile(ctypes.byref(_tile_desc(n, h, w, cin, cout, kh, kw, stride, pad, x_s2d)))
 
 
-def s2d_k_order(cin, device):
-    """K-column order of an ``x_s2d`` conv's weights (cer_conv_s2d_k_order) as an index tensor."""
+def conv2d_n16_tile(n, h, w, cin, cout, kh, kw, stride, pad, x_s2d=False):
+    """The narrow kernel variant ``conv2d_n16`` would launch for this conv (cer_conv2d_n16_tile)."""
+    return _lib.load().cer_conv2d_n16_tile(ctypes.byref(_tile_desc(n, h, w, cin, cout, kh, kw, stride, pad, x_s2d)))
+
+
+# the window / patch kernels: their epilogues can store space-to-depth
+S2D_PRODUCER_TILES = (53, 56, 58, 59)
+S2D_PRODUCER_TILES_N16 = (71, 72, 73, 76, 77, 78)
+
+
+def s2d_k_order(cin, device, chunk=32):
+    """K-column order of an ``x_s2d`` conv's weights (cer_conv_s2d_k_order) as an index tensor; chunk = channels per kernel
+    step: 32 (bf16x3) or 64 (narrow)."""
     order = (ctypes.c_int32 * (9 * cin))()
-    check(_lib.load().cer_conv_s2d_k_order(cin, order), "cer_conv_s2d_k_order")
+    check(_lib.load().cer_conv_s2d_k_order(cin, chunk, order), "cer_conv_s2d_k_order")
     return torch.tensor(list(order), dtype=torch.long, device=device)
 
 
-def pack_s2d_weight(w, cin):
-    """Packed 3x3 weights [Cout, 9*Cin] (fp32 tensor, Split or narrow plane) -> the same columns in the step order of the
-    space-to-depth stride-2 kernel."""
-    idx = s2d_k_order(cin, (w.hi if isinstance(w, Split) else w).device)
+def pack_s2d_weight(w, cin, chunk=None):
+    """Packed 3x3 weights [Cout, 9*Cin] (Split, or a narrow / fp32 plane) -> the same columns in the step order of the
+    space-to-depth stride-2 kernel (chunk: 32 for Split operands, 64 for a narrow plane)."""
     if isinstance(w, Split):
+        idx = s2d_k_order(cin, w.hi.device, chunk or 32)
         return Split(w.hi.index_select(1, idx).contiguous(), w.lo.index_select(1, idx).contiguous())
-    return w.index_select(1, idx).contiguous()
+    return w.index_select(1, s2d_k_order(cin, w.device, chunk or 64)).contiguous()
 
 
 def space_to_depth(x):
@@ -354,15 +366,20 @@ def from_n16(x):
 
 def conv2d_n16(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bias=None, alpha=None, residual=None,
                res_stride=1, act1=ACT_NONE, act2=ACT_NONE, slope=LEAKY_SLOPE, split_k=1, tile=0, out_f32=False,
-               out_n16=True, want_stats=False, bias9=None):
+               out_n16=True, want_stats=False, bias9=None, x_s2d=False, y_s2d=False):
     """Narrow convolution: x [N,H,W,Cin] and w [Cout,Kpad] are bf16 / float16 tensors of the same dtype (one MFMA per
-    product, fp32 accumulate); residual: narrow or fp32.  Returns a dict with 'n16' (narrow output), 'y' (fp32), 'stats'."""
+    product, fp32 accumulate); residual: narrow or fp32.  Returns a dict with 'n16' (narrow output), 'y' (fp32), 'stats'.
+    ``x_s2d`` / ``y_s2d``: space-to-depth input / narrow output, as in ``conv2d_b3`` (weights: ``pack_s2d_weight(w, cin, 64)``)."""
     lib = _lib.load()
     _dev_n16(x, "x")
     _dev_n16(w, "w", x.dtype)
     _dev_f32(bias, "bias")
     _dev_f32(alpha, "alpha")
     n, h, wd, cin = x.shape
+    if x_s2d:
+        if cin % 4:
+            raise ValueError("a space-to-depth input has 4 * Cin channels")
+        h, wd, cin = 2 * h, 2 * wd, cin // 4
     cout = w.shape[0]
     if w.shape[1] != conv_kpad(kh, kw, cin):
         raise ValueError(f"packed weight has K={w.shape[1]}, expected {conv_kpad(kh, kw, cin)}")
@@ -377,6 +394,7 @@ def conv2d_n16(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, b
     d.res_stride, d.Hr, d.Wr = res_stride, 0, 0
     d.act1, d.act2, d.slope, d.split_k, d.tile = act1, act2, slope, split_k, tile
     d.storage = storage_of(x.dtype)
+    d.x_s2d, d.y_s2d = int(x_s2d), int(y_s2d)
     io = ConvIO()
     io.x_hi, io.w_hi = x.data_ptr(), w.data_ptr()
     io.bias = bias.data_ptr() if bias is not None else None
@@ -403,7 +421,7 @@ def conv2d_n16(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, b
         res["y"] = torch.empty((n, ho, wo, cout), device=dev, dtype=torch.float32)
         io.y = res["y"].data_ptr()
     if out_n16:
-        res["n16"] = torch.empty((n, ho, wo, cout), device=dev, dtype=x.dtype)
+        res["n16"] = torch.empty((n, ho // 2, wo // 2, 4 * cout) if y_s2d else (n, ho, wo, cout), device=dev, dtype=x.dtype)
         io.y_hi = res["n16"].data_ptr()
     if want_stats:
         res["stats"] = torch.empty((lib.cer_conv2d_stats_tiles(ctypes.byref(d), 2), 2, cout), device=dev, dtype=torch.float32)

@@ -444,6 +444,8 @@ class IR50(nn.Module):
             d["a1"] = u.res_layer[2].weight.detach().contiguous()
             s2, b2 = self._bn_affine(u.res_layer[4])
             d["w2"] = ops.to_n16(ops.pack_conv_weight(u.res_layer[3].weight.detach().contiguous(), s2), dtype)
+            if u.stride == 2 and u.depth % 128 == 0:   # the same columns in the space-to-depth kernel's step order
+                d["w2_s2d"] = ops.pack_s2d_weight(d["w2"], u.depth)
             d["b2"] = b2
             if d["proj"]:
                 ss, sb = self._bn_affine(u.shortcut_layer[1])
@@ -473,6 +475,8 @@ class IR50(nn.Module):
         for u in self.body:
             d = {"w1_f32": ops.pack_conv_weight(u.res_layer[1].weight.detach().contiguous()),
                  "w2": ops.to_n16(ops.pack_conv_weight(u.res_layer[3].weight.detach().contiguous()), dtype)}
+            if u.stride == 2 and u.depth % 128 == 0:
+                d["w2_s2d"] = ops.pack_s2d_weight(d["w2"], u.depth)
             if u.cin != u.depth:
                 d["ws"] = ops.to_n16(ops.pack_conv_weight(u.shortcut_layer[0].weight.detach().contiguous()), dtype)
             P["units"].append(d)
@@ -489,12 +493,14 @@ class IR50(nn.Module):
                         act1=ops.ACT_PRELU, x_nchw=True, want_f32=False, out_n16=dtype)["n16"]
         for d in P["units"]:
             s = d["stride"]
-            t = ops.conv2d_n16(xs, d["w1"], 3, 3, pad=(1, 1), bias9=d["b9"], alpha=d["a1"], act1=ops.ACT_PRELU)["n16"]
+            s2d = "w2_s2d" in d and self._s2d_pair_ok(tuple(xs.shape), d["w2"].shape[0], narrow=True)
+            t = ops.conv2d_n16(xs, d["w1"], 3, 3, pad=(1, 1), bias9=d["b9"], alpha=d["a1"], act1=ops.ACT_PRELU, y_s2d=s2d)["n16"]
+            w2 = d["w2_s2d"] if s2d else d["w2"]
             if d["proj"]:
                 sc = ops.conv2d_n16(xs, d["ws"], 1, 1, stride=s, bias=d["bs"])["n16"]
-                xs = ops.conv2d_n16(t, d["w2"], 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=sc, res_stride=1)["n16"]
+                xs = ops.conv2d_n16(t, w2, 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=sc, res_stride=1, x_s2d=s2d)["n16"]
             else:
-                xs = ops.conv2d_n16(t, d["w2"], 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=xs, res_stride=s)["n16"]
+                xs = ops.conv2d_n16(t, w2, 3, 3, stride=s, pad=(1, 1), bias=d["b2"], residual=xs, res_stride=s, x_s2d=s2d)["n16"]
         n, h, w, c = xs.shape
         if h != self.head_hw or w != self.head_hw:
             raise RuntimeError(f"IR50 head was built for {self.head_hw}x{self.head_hw} feature maps "
@@ -533,9 +539,10 @@ class IR50(nn.Module):
             last = i + 1 == first_released  # the next consumer (released unit or head) wants fp32
             s1, t1 = self._finalize(xst, ys.numel() // u.cin, u.res_layer[0])
             w1, b9 = ops.fold_bn_3x3_packed(d["w1_f32"], s1, t1, dtype)
+            s2d = "w2_s2d" in d and self._s2d_pair_ok(tuple(ys.shape), u.depth, narrow=True)
             tt = ops.conv2d_n16(ys, w1, 3, 3, pad=(1, 1), alpha=u.res_layer[2].weight.detach(),
-                                act1=ops.ACT_PRELU, bias9=b9)["n16"]
-            r = ops.conv2d_n16(tt, d["w2"], 3, 3, stride=u.stride, pad=(1, 1), want_stats=True)
+                                act1=ops.ACT_PRELU, bias9=b9, y_s2d=s2d)["n16"]
+            r = ops.conv2d_n16(tt, d["w2_s2d"] if s2d else d["w2"], 3, 3, stride=u.stride, pad=(1, 1), want_stats=True, x_s2d=s2d)
             del tt
             z = r["n16"]
             cnt = z.numel() // u.depth
@@ -575,15 +582,23 @@ class IR50(nn.Module):
     _S2D_OK = {}
 
     @classmethod
-    def _s2d_pair_ok(cls, xshape, depth):
+    def _s2d_pair_ok(cls, xshape, depth, narrow=False):
         """Can the two 3x3 convs of a stride-2 unit hand their intermediate over space-to-depth?  The first conv (xshape ->
         depth, stride 1) has to run on a window / patch kernel (their epilogues can permute the stores) and the second one
-        needs even H and W, depth % 64 == 0 and Wo <= 126 (csrc/conv_b3_s2d.hip); otherwise the flat stride-2 kernel runs."""
-        key = (xshape, depth)
+        needs even H and W, depth % 64 == 0 (narrow storage: % 128) and Wo <= 126 (csrc/conv_b3_s2d.hip, conv_n16_s2d.hip);
+        otherwise the flat stride-2 kernel runs."""
+        key = (xshape, depth, narrow)
         if key not in cls._S2D_OK:
             n, h, w, cin = xshape
-            cls._S2D_OK[key] = h % 2 == 0 and w % 2 == 0 and depth % 64 == 0 and w // 2 <= 126 and cin % 32 == 0 and \
-                ops.conv2d_b3_tile(n, h, w, cin, depth, 3, 3, 1, (1, 1)) in ops.S2D_PRODUCER_TILES
+            ok = h % 2 == 0 and w % 2 == 0 and depth % (128 if narrow else 64) == 0 and w // 2 <= 126 and cin % (64 if narrow else 32) == 0
+            if ok and narrow:
+                # measured (tools/bench_s2d.py --n16): the flat 256x256 tile already runs the >= 256-cout stride-2 layers at
+                # 0.40-0.45 of the ceiling and the space-to-depth twin is within +-5 % of it; only the 128-cout layer (flat:
+                # the 128x128 tile) gains (x1.10 @224x224, x1.26 @80x80)
+                ok = depth == 128 and ops.conv2d_n16_tile(n, h, w, cin, depth, 3, 3, 1, (1, 1)) in ops.S2D_PRODUCER_TILES_N16
+            elif ok:
+                ok = ops.conv2d_b3_tile(n, h, w, cin, depth, 3, 3, 1, (1, 1)) in ops.S2D_PRODUCER_TILES
+            cls._S2D_OK[key] = ok
         return cls._S2D_OK[key]
 
     def _forward_b3(self, x):

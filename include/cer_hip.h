@@ -93,16 +93,18 @@ typedef struct cer_conv_desc {
      *       ys[n][i][j][blk*Cout + c] = y[n][2i+py][2j+px][c], blk = 3 - 2*py - px -- same bytes, the stores permuted.
      *       Window / patch kernels only (3x3 / stride 1 / pad 1), even Ho and Wo, no fp32 / second output, no residual.
      *   x_s2d != 0: x_hi / x_lo are such a tensor standing for the [N, H, W, Cin] input of THIS 3x3 / stride 2 / pad 1
-     *       conv (H, W even, Cin % 64 == 0, Wo <= 126, x_ld = 0), and the K columns of w are in the kernel's step order
-     *       (cer_conv_s2d_k_order).  The conv then runs window-resident (conv_b3_s2d_kernel) instead of gathering nine
-     *       tap tiles per channel chunk. */
+     *       conv (H, W even, Cin % 64 == 0 -- narrow storage: % 128 --, Wo <= 126, x_ld = 0), and the K columns of w are
+     *       in the kernel's step order (cer_conv_s2d_k_order).  The conv then runs window-resident (conv_b3_s2d_kernel /
+     *       conv_n16_s2d_kernel) instead of gathering nine tap tiles per channel chunk.
+     *   Split (bf16x3) and narrow operands only. */
     int32_t x_s2d, y_s2d;
 } cer_conv_desc;
 
 int cer_conv_kpad(int KH, int KW, int Cin);
 /* K-column order of the weights of an x_s2d conv: order[j] (j < 9*Cin) = the column (kh*3 + kw)*Cin + c of the ordinary
- * [Cout][9*Cin] layout that column j of the permuted matrix holds.  Host array of 9*Cin ints; Cin % 64 == 0. */
-int cer_conv_s2d_k_order(int Cin, int32_t *order);
+ * [Cout][9*Cin] layout that column j of the permuted matrix holds.  chunk = 32 (bf16x3 operands) or 64 (narrow storage):
+ * the channels of one kernel step; Cin % (2*chunk) == 0.  Host array of 9*Cin ints. */
+int cer_conv_s2d_k_order(int Cin, int chunk, int32_t *order);
 size_t cer_conv2d_workspace_bytes(const cer_conv_desc *d);
 /* rows of `stats` the launch will write; kernel_family: 0 = fp32 kernel, 1 = bf16x3 (split operands), 2 = narrow (n16) */
 int cer_conv2d_stats_tiles(const cer_conv_desc *d, int kernel_family);

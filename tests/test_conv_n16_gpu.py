@@ -301,3 +301,60 @@ def test_specialised_row_epilogues_on_every_narrow_kernel_family(kind, tile, hw,
                            tile=tile)
     got = r["n16"].float().cpu().permute(0, 3, 1, 2).double()
     assert ((got - ref).abs() <= ulp * ref.abs() + 3e-5).all(), ((got - ref).abs() - ulp * ref.abs()).max().item()
+
+
+# ---- space-to-depth hand-over of the stride-2 units (narrow twins of the bf16x3 tests) ----
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,cin,cout,h,w,tile", [(2, 64, 64, 32, 48, 71), (1, 128, 128, 16, 32, 72), (1, 128, 128, 16, 32, 78),
+                                                 (3, 64, 128, 20, 12, 76), (5, 128, 40, 10, 6, 73), (2, 64, 64, 14, 6, 77)])
+def test_narrow_producer_writes_the_space_to_depth_layout(n, cin, cout, h, w, tile, dtype):
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(n + cin + h)
+    x = torch.randn(n, h, w, cin, generator=g).to(dtype).cuda()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).to(dtype)
+    b9, alpha = torch.randn(9, cout, generator=g).cuda(), (torch.rand(cout, generator=g) * 0.3 + 0.1).cuda()
+    wd = ops.to_n16(ops.pack_conv_weight(wt.float().cuda()), dtype)
+    kw = dict(pad=(1, 1), bias9=b9, alpha=alpha, act1=ops.ACT_PRELU, tile=tile)
+    plain = ops.conv2d_n16(x, wd, 3, 3, **kw)["n16"]
+    s2d = ops.conv2d_n16(x, wd, 3, 3, y_s2d=True, **kw)["n16"]
+    assert tuple(s2d.shape) == (n, h // 2, w // 2, 4 * cout)
+    assert torch.equal(s2d, ops.space_to_depth(plain))                   # the same values, the stores permuted
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,cin,cout,h,w", [
+    (3, 128, 128, 16, 16), (2, 128, 128, 40, 40), (1, 256, 200, 12, 10), (7, 512, 512, 10, 10), (1, 128, 128, 224, 224),
+    (1, 128, 40, 4, 252), (5, 128, 256, 6, 2), (9, 128, 64, 2, 2), (1, 256, 128, 34, 30)])
+def test_narrow_stride2_conv_on_a_space_to_depth_input(n, cin, cout, h, w, dtype):
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(n * 7 + cin + cout + h)
+    x = torch.randn(n, cin, h, w, generator=g).to(dtype)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).to(dtype)
+    ref = F.conv2d(x.double(), wt.double(), None, 2, 1)
+    mag = F.conv2d(x.double().abs(), wt.double().abs(), None, 2, 1)
+    xd, wd = _dev(x, wt)
+    r = ops.conv2d_n16(ops.space_to_depth(xd), ops.pack_s2d_weight(wd, cin), 3, 3, stride=2, pad=(1, 1), x_s2d=True,
+                       out_f32=True, out_n16=True, want_stats=True)
+    got = r["y"].cpu().permute(0, 3, 1, 2).double()
+    assert tuple(got.shape) == tuple(ref.shape)
+    bound = mag * (cin * 9 * 2.0 ** -24) + 1e-9                          # exact products, fp32 accumulation
+    assert ((got - ref).abs() <= bound).all(), ((got - ref).abs() / bound).max().item()
+    assert torch.equal(r["n16"].cpu(), r["y"].cpu().to(dtype))
+    st = r["stats"].cpu().double().sum(0)
+    assert (st[0] - ref.sum((0, 2, 3))).abs().max().item() < 1e-2 * max(1.0, (n * h * w / 400) ** 0.5)
+    assert (st[1] - (ref * ref).sum((0, 2, 3))).abs().max().item() < 1e-2 * max(1.0, n * h * w / 400)
+
+
+def test_narrow_space_to_depth_errors_are_loud():
+    from feature_vs_text_compound_emotion_amd import ops
+    dt = torch.float16
+    x = torch.randn(2, 10, 10, 4 * 64).to(dt).cuda()                     # Cin = 64: one chunk per phase is not supported
+    w = torch.randn(64, 9 * 64).to(dt).cuda()
+    with pytest.raises(RuntimeError, match="Cin % 128"):
+        ops.conv2d_n16(x, w, 3, 3, stride=2, pad=(1, 1), x_s2d=True)
+    x = torch.randn(2, 10, 10, 4 * 128).to(dt).cuda()
+    w = torch.randn(64, 9 * 128).to(dt).cuda()
+    with pytest.raises(RuntimeError, match="space-to-depth"):            # a flat tile cannot read the layout
+        ops.conv2d_n16(x, w, 3, 3, stride=2, pad=(1, 1), x_s2d=True, tile=94)
+    with pytest.raises(RuntimeError, match="y_s2d"):                     # ... or write it
+        ops.conv2d_n16(torch.randn(2, 10, 10, 128).to(dt).cuda(), w, 3, 3, pad=(1, 1), y_s2d=True, tile=94)

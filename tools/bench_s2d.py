@@ -27,9 +27,29 @@ def main():
     ap.add_argument("--frames", type=int, default=1024)
     ap.add_argument("--hw", type=int, default=224, help="input frame size (the four stride-2 layers see hw, hw/2, hw/4, hw/8)")
     ap.add_argument("--iters", type=int, default=5)
+    ap.add_argument("--n16", choices=["bf16", "fp16"], default=None, help="narrow kernels (one 16-bit plane per operand)")
     a = ap.parse_args()
+    if a.n16:
+        dt = torch.bfloat16 if a.n16 == "bf16" else torch.float16
+        for i, c in enumerate((128, 256, 512)):
+            h = a.hw >> i
+            if h % 2:
+                continue
+            x = ops.to_n16(torch.randn(a.frames, h, h, c, device="cuda"), dt)
+            w = ops.to_n16(torch.randn(c, 9 * c, device="cuda") * 0.02, dt)
+            xs, ws = ops.space_to_depth(x), ops.pack_s2d_weight(w, c)
+            flops = 2.0 * a.frames * (h // 2) ** 2 * c * c * 9
+            kw = dict(stride=2, pad=(1, 1), want_stats=True)
+            t_flat = timed(lambda: ops.conv2d_n16(x, w, 3, 3, **kw), a.iters)
+            t_s2d = timed(lambda: ops.conv2d_n16(xs, ws, 3, 3, x_s2d=True, **kw), a.iters)
+            print(f"{c:4d}->{c:<4d} @{h:3d}^2 s2 {a.n16}: flat {t_flat:7.3f} ms {flops / t_flat / 1e9:6.1f} TF/s | "
+                  f"s2d {t_s2d:7.3f} ms {flops / t_s2d / 1e9:6.1f} TF/s  x{t_flat / t_s2d:.2f}", flush=True)
+            del x, w, xs, ws
+        return
     for i, c in enumerate((64, 128, 256, 512)):
         h = a.hw >> i
+        if h % 2:
+            continue
         x = ops.split_bf16(torch.randn(a.frames, h, h, c, device="cuda"))
         w = ops.split_bf16(torch.randn(c, 9 * c, device="cuda") * 0.02)
         xs, ws = ops.space_to_depth(x), ops.pack_s2d_weight(w, c)
