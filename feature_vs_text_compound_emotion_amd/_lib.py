@@ -40,6 +40,8 @@ _SIGNATURES = {
     "cer_version": (c_int, []),
     "cer_conv_kpad": (c_int, [c_int, c_int, c_int]),
     "cer_conv_s2d_k_order": (c_int, [c_int, c_int, POINTER(c_int32)]),
+    "cer_stem_conv3x3_stats_rows": (c_int, [c_int, c_int]),
+    "cer_stem_conv3x3": (c_int, [_P, _P, c_int, _P, _P, _P, _P, _P, _P, c_int, _P, c_int, c_int, c_int, _P]),
     "cer_conv2d_workspace_bytes": (c_size_t, [POINTER(ConvDesc)]),
     "cer_conv2d_stats_tiles": (c_int, [POINTER(ConvDesc), c_int]),
     "cer_conv2d_run": (c_int, [POINTER(ConvDesc), POINTER(ConvIO), _P, c_size_t, _P]),

@@ -301,6 +301,67 @@ __device__ __forceinline__ void epi_store4(const ConvArgs &p, const EpiCtx &e, i
 }
 
 
+// epi_store4's fast path for kernels whose threads call the epilogue with MANY channel groups (the fp32 igemm kernel: 8-16
+// groups of 4 couts per thread, so an EpiCtx per group would not fit the registers): the per-channel constants are re-loaded
+// per call (L1 hits).  The Cin = 3 stem at 224x224 spent its time in epilogue_store4's branch skeleton (~2 600 instructions
+// per call, 8 calls per thread, 400 000 tiles): 10.5 ms for a launch whose HBM floor is 2.8 ms.
+__device__ __forceinline__ bool epi_fast(const ConvArgs &p) {
+    return (p.Cout & 3) == 0 && (p.y_ld & 3) == 0 && p.act2 == CER_ACT_NONE &&
+           (p.act1 == CER_ACT_NONE || p.act1 == CER_ACT_PRELU || p.act1 == CER_ACT_RELU) && !p.mask && !p.aux && !p.y2_hi;
+}
+
+__device__ __forceinline__ void epi_store4_direct(const ConvArgs &p, bool fast, int m, int c, float v[4]) {
+    if (!fast || c + 3 >= p.Cout) {
+        epilogue_store4(p, m, c, v);
+        return;
+    }
+    float o[4] = {v[0], v[1], v[2], v[3]};
+    const float *bias = p.bias9 ? p.bias9 + (size_t)bias9_case(p, m) * p.Cout : p.bias;
+    if (bias) {
+        const float4 b = *reinterpret_cast<const float4 *>(bias + c);
+        o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w;
+    }
+    if (p.act1 == CER_ACT_PRELU) {
+        const float4 a = *reinterpret_cast<const float4 *>(p.alpha + c);
+        o[0] = o[0] >= 0.f ? o[0] : o[0] * a.x; o[1] = o[1] >= 0.f ? o[1] : o[1] * a.y;
+        o[2] = o[2] >= 0.f ? o[2] : o[2] * a.z; o[3] = o[3] >= 0.f ? o[3] : o[3] * a.w;
+    } else if (p.act1 == CER_ACT_RELU) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] = o[t] > 0.f ? o[t] : 0.f;
+    }
+    if (p.res || p.res_hi) {
+        size_t roff;
+        if (p.res_stride == 1 && p.Hr == p.Ho && p.Wr == p.Wo) {
+            roff = (size_t)m * p.Cout + c;
+        } else {
+            const int hw = p.Ho * p.Wo;
+            const int n = m / hw, r = m - n * hw;
+            const int ho = r / p.Wo, wo = r - ho * p.Wo;
+            roff = ((size_t)(n * p.Hr + ho * p.res_stride) * p.Wr + wo * p.res_stride) * p.Cout + c;
+        }
+        float rr[4];
+        if (p.res) {
+            const float4 r = *reinterpret_cast<const float4 *>(p.res + roff);
+            rr[0] = r.x; rr[1] = r.y; rr[2] = r.z; rr[3] = r.w;
+        } else if (p.narrow) {
+            load_narrow4(p.res_hi + roff, rr, p.narrow);
+        } else {
+            const ushort4 h = *reinterpret_cast<const ushort4 *>(p.res_hi + roff);
+            const ushort4 l = *reinterpret_cast<const ushort4 *>(p.res_lo + roff);
+            rr[0] = bf16_to_f32(h.x) + bf16_to_f32(l.x); rr[1] = bf16_to_f32(h.y) + bf16_to_f32(l.y);
+            rr[2] = bf16_to_f32(h.z) + bf16_to_f32(l.z); rr[3] = bf16_to_f32(h.w) + bf16_to_f32(l.w);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; ++t) o[t] += rr[t];
+    }
+    const size_t yoff = (size_t)m * p.y_ld + c;
+    if (p.y) *reinterpret_cast<float4 *>(p.y + yoff) = make_float4(o[0], o[1], o[2], o[3]);
+    if (p.y_hi) {
+        if (p.narrow) store_narrow4(p.y_hi + yoff, o, p.narrow);
+        else store_split4(p.y_hi + yoff, p.y_lo + yoff, o);
+    }
+}
+
 // ---- fully specialised row epilogues for the encoder's launches ----
 // Even the streamlined epi_store4 spends ~20 uniform branches per 4 couts.  The launches that carry the encoder's time use six
 // exact combinations; epi_mode names them once per launch and epi_row<MODE> is straight-line code (~25 instructions):

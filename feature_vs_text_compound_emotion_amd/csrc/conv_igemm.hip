@@ -261,6 +261,7 @@ __global__ __launch_bounds__(WP * WC * 64, 3) void conv_igemm_kernel(ConvArgs p)
 
     // ---- epilogue: D[i = cout][j = pixel]; reg r -> cout (r&3) + 8*(r>>2) + 4*half ----
     // (compile-time indices: a runtime-indexed accumulator array would live in scratch)
+    const bool fast = epi_fast(p);   // one uniform decision per launch; the general epilogue otherwise
     static_for<TP>([&](auto B) {
         constexpr int b = decltype(B)::v;
         const int m = m0 + (wp * TP + b) * 32 + l31;
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(WP * WC * 64, 3) void conv_igemm_kernel(ConvArgs p)
                                 if (c + e < p.Cout) dst[e] = v[e];
                         }
                     } else {
-                        epilogue_store4(p, m, c, v);
+                        epi_store4_direct(p, fast, m, c, v);
                     }
                 }
             });
@@ -349,7 +350,7 @@ __global__ void splitk_reduce_kernel(ConvArgs p, const float *partial) {
                 if (c + e < p.Cout) v[e] += src[e];
         }
     }
-    epilogue_store4(p, m, c, v);
+    epi_store4_direct(p, epi_fast(p), m, c, v);
 }
 
 // ---------------------------------------------------------------- host side

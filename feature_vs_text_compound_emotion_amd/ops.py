@@ -279,6 +279,38 @@ def conv2d_b3(x, w, kh, kw, *, stride=1, dil=(1, 1), pad=(0, 0), out_hw=None, bi
     return res
 
 
+def stem_conv(x, w, scale=None, shift=None, alpha=None, out=None, want_stats=False):
+    """IR-50 input layer on the vector ALUs (cer_stem_conv3x3).  x [N,3,H,W] fp32 (NCHW), w the packed [64, Kpad] weight.
+    ``out`` = None: the statistics pass -- returns the [rows,2,64] partial sums of the RAW conv result.  Otherwise ``out`` is
+    "f32", "split", torch.bfloat16 or torch.float16 and the result is ``prelu(conv*scale+shift, alpha)`` in that storage,
+    returned as a dict with 'y' / 'split' / 'n16' and (``want_stats``) 'stats' of that output."""
+    _dev_f32(x, "x")
+    _dev_f32(w, "w")
+    for t, nme in ((scale, "scale"), (shift, "shift"), (alpha, "alpha")):
+        _dev_f32(t, nme)
+    n, c, h, wd = x.shape
+    if c != 3 or w.shape[0] != 64:
+        raise ValueError("stem_conv is the 3 -> 64 input layer")
+    lib = _lib.load()
+    stats = _empty((lib.cer_stem_conv3x3_stats_rows(n, h), 2, 64), x) if (want_stats or out is None) else None
+    res, y, hi, lo, storage = {}, None, None, None, STORE_NONE
+    if out == "f32":
+        res["y"] = y = torch.empty((n, h, wd, 64), device=x.device, dtype=torch.float32)
+    elif out == "split":
+        res["split"] = Split.empty((n, h, wd, 64), x.device)
+        hi, lo = res["split"].hi, res["split"].lo
+    elif out is not None:
+        storage = storage_of(out)
+        res["n16"] = hi = torch.empty((n, h, wd, 64), device=x.device, dtype=out)
+    check(lib.cer_stem_conv3x3(ptr(x), ptr(w), w.shape[1], ptr(scale), ptr(shift), ptr(alpha), ptr(y), ptr(hi), ptr(lo), storage,
+                               ptr(stats), n, h, wd, current_stream()), "cer_stem_conv3x3")
+    if out is None:
+        return stats
+    if want_stats:
+        res["stats"] = stats
+    return res
+
+
 def _tile_desc(n, h, w, cin, cout, kh, kw, stride, pad, x_s2d):
     d = ConvDesc()
     d.N, d.H, d.W, d.Cin, d.Cout = n, h, w, cin, cout

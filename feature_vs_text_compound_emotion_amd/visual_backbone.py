@@ -235,6 +235,8 @@ class IR50(nn.Module):
     def __init__(self, input_channels=3, drop_ratio=0.4, head_hw=5, embedding_dim=512):
         super().__init__()
         self.head_hw = head_hw
+        if input_channels != 3:
+            raise NotImplementedError("the input layer kernel (csrc/stem_conv.hip) is the reference's 3-channel one")
         self.input_layer = nn.Sequential(nn.Conv2d(input_channels, 64, 3, 1, 1, bias=False), nn.BatchNorm2d(64),
                                          nn.PReLU(64))
         self.output_layer = nn.Sequential(nn.BatchNorm2d(embedding_dim), nn.Dropout(drop_ratio), _Flatten(),
@@ -489,8 +491,7 @@ class IR50(nn.Module):
     def _forward_n16(self, x, dtype):
         """Eval / frozen forward on the narrow kernels (Cin = 3 stem on the fp32 small-Cin kernel, narrow output)."""
         P = self.pack_n16(dtype)
-        xs = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), bias=P["stem_b"], alpha=P["stem_a"],
-                        act1=ops.ACT_PRELU, x_nchw=True, want_f32=False, out_n16=dtype)["n16"]
+        xs = ops.stem_conv(x.contiguous(), P["stem_w"], None, P["stem_b"], P["stem_a"], out=dtype)["n16"]
         for d in P["units"]:
             s = d["stride"]
             s2d = "w2_s2d" in d and self._s2d_pair_ok(tuple(xs.shape), d["w2"].shape[0], narrow=True)
@@ -526,10 +527,11 @@ class IR50(nn.Module):
         if plan is not None and self._stem_released():
             y = self._released_stem(x)
         else:
-            r = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True, want_f32=False, out_n16=dtype)
-            s, t = self._finalize(r["stats"], r["n16"].numel() // 64, self.input_layer[1])
-            r = ops.bn_apply_nhwc_n16(r["n16"], s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True,
-                                      out_f32=first_released == 0, out_n16=first_released != 0)
+            # the input layer is write-bound: statistics pass, then the conv again with BatchNorm + PReLU applied (stem_conv.hip)
+            xc = x.contiguous()
+            s, t = self._finalize(ops.stem_conv(xc, P["stem_w"]), n * x.shape[2] * x.shape[3], self.input_layer[1])
+            r = ops.stem_conv(xc, P["stem_w"], s, t, self.input_layer[2].weight.detach(),
+                              out="f32" if first_released == 0 else dtype, want_stats=True)
             ys, xst, y = r.get("n16"), r["stats"], r.get("y")
             del r
         for i, (u, d) in enumerate(zip(self.body, P["units"])):
@@ -605,8 +607,7 @@ class IR50(nn.Module):
         """Eval / frozen forward on the bf16x3 kernels (Cin = 3 stem on the fp32 small-Cin kernel)."""
         P = self.pack_b3()
         U = P["units"]
-        xs = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), bias=P["stem_b"], alpha=P["stem_a"],
-                        act1=ops.ACT_PRELU, x_nchw=True, want_f32=False, out_split=True)["split"]
+        xs = ops.stem_conv(x.contiguous(), P["stem_w"], None, P["stem_b"], P["stem_a"], out="split")["split"]
         for d in U:
             s = d["stride"]
             s2d = "w2_s2d" in d and self._s2d_pair_ok(tuple(xs.shape), d["w2"].shape[0])
@@ -642,12 +643,13 @@ class IR50(nn.Module):
         if plan is not None and self._stem_released():
             y = self._released_stem(x)
         else:
-            y0, st = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True)
-            s, t = self._finalize(st, y0.numel() // 64, self.input_layer[1])
-            r = ops.bn_apply_nhwc_b3(y0, s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True,
-                                     out_f32=first_released == 0, out_split=first_released != 0)
+            # the input layer is write-bound: statistics pass, then the conv again with BatchNorm + PReLU applied (stem_conv.hip)
+            xc = x.contiguous()
+            s, t = self._finalize(ops.stem_conv(xc, P["stem_w"]), n * x.shape[2] * x.shape[3], self.input_layer[1])
+            r = ops.stem_conv(xc, P["stem_w"], s, t, self.input_layer[2].weight.detach(),
+                              out="f32" if first_released == 0 else "split", want_stats=True)
             ys, xst, y = r.get("split"), r["stats"], r.get("y")
-            del y0, r
+            del r
         for i, (u, d) in enumerate(zip(self.body, P["units"])):
             if i >= first_released:  # released for training: fp32 tensors, bf16x3 forward / data-gradient convs, with a backward
                 y = self._released_unit(u, y, "bf16x3")
@@ -772,10 +774,10 @@ class IR50(nn.Module):
         if plan is not None and self._stem_released():
             y = self._released_stem(x)
         else:
-            y0, st = ops.conv2d(x.contiguous(), P["stem_w"], 3, 3, pad=(1, 1), x_nchw=True, want_stats=True)
-            s, t = self._finalize(st, y0.numel() // 64, self.input_layer[1])
-            y, xst = ops.bn_apply_nhwc(y0, s, t, alpha=self.input_layer[2].weight.detach(), want_stats=True)
-            del y0
+            xc = x.contiguous()
+            s, t = self._finalize(ops.stem_conv(xc, P["stem_w"]), x.shape[0] * x.shape[2] * x.shape[3], self.input_layer[1])
+            r = ops.stem_conv(xc, P["stem_w"], s, t, self.input_layer[2].weight.detach(), out="f32", want_stats=True)
+            y, xst = r["y"], r["stats"]
         for i, (u, d) in enumerate(zip(self.body, P["units"])):
             if i >= first_released:
                 y = self._released_unit(u, y)
@@ -846,8 +848,7 @@ class IR50(nn.Module):
             return self._forward_b3(x)
         P = self.pack()
         x = x.contiguous()
-        y = ops.conv2d(x, P["stem_w"], 3, 3, pad=(1, 1), bias=P["stem_b"], alpha=P["stem_a"],
-                       act1=ops.ACT_PRELU, x_nchw=True)
+        y = ops.stem_conv(x, P["stem_w"], None, P["stem_b"], P["stem_a"], out="f32")["y"]
         for d in P["units"]:
             s = d["stride"]
             t = ops.conv2d(y, d["w1"], 3, 3, pad=(1, 1), in_scale=d["in_s"], in_shift=d["in_b"], alpha=d["a1"],

@@ -180,6 +180,21 @@ int cer_l2norm_rows(const float *x, float *y, int rows, int cols, void *stream);
 int cer_l2norm_rows_bwd(const float *dy, const float *x, float *dx, int rows, int cols, void *stream);
 
 /* max-pool 2x2 stride 2 on NHWC (reference models/backbone.py:45-46). */
+/* ------------------------------------------------------------------------
+ * IR-50 input layer: Conv2d(3, 64, 3x3, stride 1, pad 1) [+ BatchNorm2d + PReLU] (reference models/arcface_model.py:130-132,
+ * :148) as a direct convolution on the vector ALUs -- the layer is write-bound (27 multiply-adds per output value), so in
+ * model.train() it is cheaper to run it twice than to store its raw result for the batch-statistics BatchNorm:
+ *   statistics pass (y, y_hi, y_lo, scale, shift, alpha all NULL): stats [cer_stem_conv3x3_stats_rows(N, H)][2][64] receives the
+ *       per-block sum / sum of squares of the RAW conv result (reduce with cer_bn_finalize);
+ *   apply pass (an output given): out = prelu(conv * scale[c] + shift[c], alpha[c]) (NULL scale / shift / alpha = 1 / 0 / none)
+ *       stored as fp32 (y) and / or split bf16 planes (y_hi, y_lo; storage = 0) or ONE narrow plane (y_hi; storage =
+ *       CER_STORE_BF16 / CER_STORE_F16); stats (optional) then receives the partial statistics of `out`.
+ * x [N, 3, H, W] fp32 (NCHW frames as the reference feeds them); w [64][Kpad] packed like every conv weight
+ * (K index = (kh*3 + kw)*3 + c, Kpad = cer_conv_kpad(3, 3, 3)); outputs NHWC [N, H, W, 64]. */
+int cer_stem_conv3x3_stats_rows(int N, int H);
+int cer_stem_conv3x3(const float *x, const float *w, int Kpad, const float *scale, const float *shift, const float *alpha,
+                     float *y, uint16_t *y_hi, uint16_t *y_lo, int storage, float *stats, int N, int H, int W, void *stream);
+
 int cer_maxpool2x2_nhwc(const float *x, float *y, int N, int H, int W, int C, void *stream);
 
 /* Video-frame input transform of the reference Dataset, fused (base/dataset.py:487-508,

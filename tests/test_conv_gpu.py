@@ -152,3 +152,49 @@ def test_output_grid_that_outruns_the_input_is_rejected():
     w = ops.pack_conv_weight(torch.randn(64, 64, 3, 3).cuda())
     with pytest.raises(RuntimeError, match="outruns"):
         ops.conv2d(x, w, 3, 3, pad=(1, 1), out_hw=(6, 6))
+
+
+# ---- the Cin = 3 input layer as a direct convolution (csrc/stem_conv.hip): statistics pass + apply pass ----
+@pytest.mark.parametrize("n,h,w", [(3, 40, 40), (2, 224, 224), (5, 7, 13), (1, 2, 2), (2, 33, 50)])
+def test_stem_conv_statistics_and_apply_passes(n, h, w):
+    from feature_vs_text_compound_emotion_amd import ops
+    g = torch.Generator().manual_seed(n + h)
+    x = torch.randn(n, 3, h, w, generator=g)
+    wt = torch.randn(64, 3, 3, 3, generator=g) / 27 ** 0.5
+    scale, shift = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g) * 0.3
+    alpha = torch.rand(64, generator=g) * 0.3 + 0.1
+    raw = F.conv2d(x.double(), wt.double(), None, 1, 1)
+    xd, wd = x.cuda(), ops.pack_conv_weight(wt.cuda())
+    st = ops.stem_conv(xd, wd)
+    assert tuple(st.shape[1:]) == (2, 64)
+    tot = st.double().cpu().sum(0)
+    cnt = n * h * w
+    assert (tot[0] - raw.sum((0, 2, 3))).abs().max().item() < 1e-5 * cnt ** 0.5 + 1e-4
+    assert (tot[1] - (raw * raw).sum((0, 2, 3))).abs().max().item() < 1e-5 * cnt + 1e-4
+    z = raw * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    ref = torch.where(z >= 0, z, z * alpha.double().view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    args = (xd, wd, scale.cuda(), shift.cuda(), alpha.cuda())
+    r = ops.stem_conv(*args, out="f32", want_stats=True)
+    assert (r["y"].double().cpu() - ref).abs().max().item() < 5e-6      # 27 fp32 multiply-adds per value
+    so = r["stats"].double().cpu().sum(0)
+    assert (so[0] - ref.sum((0, 1, 2))).abs().max().item() < 1e-5 * cnt ** 0.5 + 1e-4
+    assert (so[1] - (ref * ref).sum((0, 1, 2))).abs().max().item() < 1e-5 * cnt + 1e-4
+    # the other storages hold the same values, rounded once
+    sp = ops.stem_conv(*args, out="split")["split"]
+    want = ops.split_bf16(r["y"])
+    assert torch.equal(sp.hi, want.hi) and torch.equal(sp.lo, want.lo)
+    for dt in (torch.bfloat16, torch.float16):
+        assert torch.equal(ops.stem_conv(*args, out=dt)["n16"], r["y"].to(dt))
+    # eval form: no scale, shift = bias; and the implicit-GEMM kernel computes the same layer
+    e = ops.stem_conv(xd, wd, None, shift.cuda(), alpha.cuda(), out="f32")["y"]
+    ig = ops.conv2d(xd, wd, 3, 3, pad=(1, 1), bias=shift.cuda(), alpha=alpha.cuda(), act1=ops.ACT_PRELU, x_nchw=True)
+    assert (e - ig).abs().max().item() < 5e-6
+
+
+def test_stem_conv_argument_errors():
+    from feature_vs_text_compound_emotion_amd import ops
+    x, w = torch.randn(1, 3, 8, 8).cuda(), torch.randn(64, 32).cuda()
+    with pytest.raises(RuntimeError, match="statistics pass"):
+        ops.stem_conv(x, w, scale=torch.ones(64).cuda())           # scale without an output tensor
+    with pytest.raises(ValueError, match="3 -> 64"):
+        ops.stem_conv(torch.randn(1, 4, 8, 8).cuda(), w)
