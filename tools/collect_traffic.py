@@ -19,7 +19,7 @@ def total(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     s, n = 0.0, 0
     for r in csv.DictReader(open(f)):
-        if any(k in r["Kernel_Name"] for k in ("conv_igemm_kernel", "conv_b3", "conv_n16")) and \
+        if any(k in r["Kernel_Name"] for k in ("conv_igemm_kernel", "conv_b3", "conv_n16", "stem_conv3x3")) and \
                 r["Counter_Name"] == counter:
             s += float(r["Counter_Value"])
             n += 1
@@ -39,7 +39,7 @@ def main():
     extra["kernel_source_sha"] = kernel_source_sha()   # bench.py reports a profile only for the code it was taken on
     f, nf = total(fetch_dir, "FETCH_SIZE")
     w, nw = total(write_dir, "WRITE_SIZE")
-    res = {"kernel": "all conv launches of one step (conv_b3_*, conv_n16_*, conv_igemm)", "steps_profiled": steps,
+    res = {"kernel": "all conv launches of one step (conv_b3_*, conv_n16_*, conv_igemm, stem_conv3x3)", "steps_profiled": steps,
            "launches_per_step": nf / steps,
            "fetch_bytes_per_step": 2.0 * f * 1024 / steps, "write_bytes_per_step": w * 1024 / steps,
            "hbm_bytes_per_step": (2.0 * f + w) * 1024 / steps,
