@@ -347,8 +347,8 @@ class Workload:
             del k["flops"], k["algo_bytes"]
         dominant = max(kernels, key=lambda n: kernels[n]["ms_per_step"]) if kernels else None
         what = {"fp32": "whole IR-50 forward on cer::conv_igemm_kernel (v_mfma_f32_32x32x2_f32)",
-                "bf16x3": "whole IR-50 forward (51 bf16x3 implicit-GEMM convs + head FC, fp32 stem, batch-statistics BatchNorm passes)",
-                }.get(cfg["precision"], "whole IR-50 forward (51 narrow implicit-GEMM convs + head FC, fp32 stem, batch-statistics "
+                "bf16x3": "whole IR-50 forward (51 bf16x3 implicit-GEMM convs + head FC, the input layer as a two-pass direct convolution, batch-statistics BatchNorm passes)",
+                }.get(cfg["precision"], "whole IR-50 forward (51 narrow implicit-GEMM convs + head FC, the input layer as a two-pass direct convolution, batch-statistics "
                                         "BatchNorm passes)")
         span = {"what": what + ": algorithmic IR-50 FLOPs of the step / HIP-event span of the encoder forward",
                 "achieved": achieved, "frac": achieved / peak, "ms_per_step_in_kernel": enc_ms, "algorithmic_flops_per_step": flops}
