@@ -122,3 +122,43 @@ def test_bench_helpers():
     t = json.load(open(os.path.join(ROOT, "profiles", "round2_traffic_bf16x3_hw224_L32.json")))
     got = bench.measured_traffic(cfg)
     assert got == (t["hbm_bytes_per_step"] if t["kernel_source_sha"] == sha else None)
+
+
+def test_space_to_depth_weight_order_and_layout_describe_the_stride2_conv():
+    """Host side of the space-to-depth stride-2 kernels: cer_conv_s2d_k_order is a permutation of the 9*C weight columns in
+    (phase, chunk, shift) step order, and a stride-1 2x2 conv over the space-to-depth tensor with those columns IS the
+    3x3 / stride 2 / pad 1 conv (torch on the CPU; the kernels are tested on the GPU)."""
+    import ctypes
+
+    import torch
+    import torch.nn.functional as F
+
+    from feature_vs_text_compound_emotion_amd import _lib, ops
+    lib = _lib.load()
+    for cin, chunk in ((64, 32), (128, 64), (128, 32)):
+        order = (ctypes.c_int32 * (9 * cin))()
+        assert lib.cer_conv_s2d_k_order(cin, chunk, order) == 0
+        order = np.array(list(order))
+        assert sorted(order.tolist()) == list(range(9 * cin))
+        taps = order.reshape(-1, chunk)[:, 0] // cin                      # the filter tap of every step
+        per_phase = [4 * cin // chunk, 2 * cin // chunk, 2 * cin // chunk, cin // chunk]
+        bounds = np.cumsum([0] + per_phase)
+        for ph, allowed in enumerate(([0, 2, 6, 8], [1, 7], [3, 5], [4])):
+            assert set(taps[bounds[ph]:bounds[ph + 1]].tolist()) == set(allowed)
+    assert lib.cer_conv_s2d_k_order(96, 32, (ctypes.c_int32 * (9 * 96))()) != 0    # an odd number of chunks per phase
+    # the algebra: phase images + per-phase shifts reproduce the strided conv
+    g = torch.Generator().manual_seed(3)
+    n, c, h, w, co = 2, 4, 8, 6, 5
+    x, wt = torch.randn(n, h, w, c, generator=g), torch.randn(co, c, 3, 3, generator=g)
+    ref = F.conv2d(x.permute(0, 3, 1, 2), wt, None, 2, 1).permute(0, 2, 3, 1)
+    xs = ops.space_to_depth(x)                                            # [n, h/2, w/2, 4c], blocks P11 | P10 | P01 | P00
+    assert tuple(xs.shape) == (n, h // 2, w // 2, 4 * c)
+    shifts = {0: [(0, 0, 0), (0, 1, 2), (1, 0, 6), (1, 1, 8)], 1: [(0, 1, 1), (1, 1, 7)], 2: [(1, 0, 3), (1, 1, 5)], 3: [(1, 1, 4)]}
+    out = torch.zeros_like(ref)
+    pad = F.pad(xs, (0, 0, 1, 0, 1, 0))                                   # one zero row above / column to the left
+    for blk, lst in shifts.items():
+        img = pad[..., blk * c:(blk + 1) * c]
+        for kh, kw, tap in lst:                                           # shift (kh - 1, kw - 1) of the phase image
+            sl = img[:, kh:kh + h // 2, kw:kw + w // 2]
+            out += torch.einsum("nhwc,oc->nhwo", sl, wt[:, :, tap // 3, tap % 3])
+    assert (out - ref).abs().max().item() < 1e-5
