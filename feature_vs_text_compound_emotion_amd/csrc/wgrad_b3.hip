@@ -45,13 +45,20 @@ __device__ __forceinline__ int wg_off(int row, int ch) { return 256 * row + 16 *
 // SPLIT_IN: dZ and X arrive as split tensors (hi / lo bf16 planes, what the released units' forward and data-gradient convs
 // consume anyway): the loader copies 8 bytes per plane instead of converting -- the conversion of fp32 operands, redone by
 // every (tile, tap) block, was half of the kernel's issue slots (PMC: "active" 51 % at MFMA busy 23 %).
-template <int TS, bool SPLIT_IN>
+// DMA (split operands, TS = 128, channel counts % 8 == 0): the planes already are what the LDS tiles hold, so the stage is
+// filled by LDS-DMA instead of through registers -- a 1-KiB piece is 4 pixel rows x 256 bytes, lane l owns row l / 16 and LDS
+// slot l % 16 and fetches the source chunk slot ^ f(row) (the swizzle of wg_off on the SOURCE address, as in the conv
+// kernels); padding taps and rows past the split are out-of-range offsets = zeros.  8 DMA instructions per wave and step
+// replace 16 eight-byte loads + 16 LDS stores + their index arithmetic.
+template <int TS, bool SPLIT_IN, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) {
+    static_assert(!DMA || (SPLIT_IN && TS == 128), "the DMA loader copies split planes into full 256-byte rows");
     constexpr int KS = 32, PLANE = KS * 256, STAGE = 4 * PLANE;       // planes per stage: dZ hi, dZ lo, X hi, X lo
     constexpr int NTW = TS / 32;                                      // 16-wide MFMA tiles per wave and side
     constexpr int LPT = TS / 32;                                      // float4 loads per thread, operand and step
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: the DMA destinations are scalar
     const int wi = wave & 1, wj = wave >> 1;
     const int kg = lane >> 4, l15 = lane & 15;
     // XCD-aware work order: the tiles x taps blocks of one row split all read the same dZ / X rows (a few MiB), so they are
@@ -177,15 +184,75 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
 #pragma unroll
             for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
 
+    // ---- DMA loader state: pieces wave + 4 i (i = 0, 1) of each plane; (n, ho, wo) of this lane's two rows ----
+    constexpr unsigned OOB = 0x80000000u;
+    const int drow = lane >> 4, dch = lane & 15;
+    int dn[2], dho[2], dwo[2];
+    if constexpr (DMA) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int r = r_begin + 4 * (wave + 4 * i) + drow;
+            dn[i] = r / hw;
+            const int q = r - dn[i] * hw;
+            dho[i] = q / p.Wo;
+            dwo[i] = q - dho[i] * p.Wo;
+        }
+    }
+    auto issue_step = [&](int r0, int buf) {
+        // uniform bases: dZ rows r0 .. r0 + 31 are contiguous; X offsets are taken from the first pixel of image n0 (the rows
+        // of a step span a few images at most, so they fit 32 bits)
+        const int n0 = __builtin_amdgcn_readfirstlane(r0 / hw);
+        const size_t zb = (size_t)r0 * p.Cout * 2, xb = (size_t)n0 * p.H * p.W * p.Cin * 2;
+        const __amdgpu_buffer_rsrc_t rzh = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.dz_hi)) + zb, 0, (int)OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rzl = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.dz_lo)) + zb, 0, (int)OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.x_hi)) + xb, 0, (int)OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.x_lo)) + xb, 0, (int)OOB, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int piece = wave + 4 * i, rl = 4 * piece + drow, r = r0 + rl;
+            const int ch = dch ^ (((rl & 3) << 2) | ((rl >> 2) & 3));      // source chunk (8 channels) for this LDS slot
+            const int hi = dho[i] * p.stride - p.pad_t + kh, wi_ = dwo[i] * p.stride - p.pad_l + kw;
+            const bool live = r < r_end;
+            const bool zin = live && co0 + ch * 8 < p.Cout;
+            const bool xin = live && ci0 + ch * 8 < p.Cin && (unsigned)hi < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.W;
+            const unsigned ao = zin ? (unsigned)(((size_t)rl * p.Cout + co0 + ch * 8) * 2) : OOB;
+            const unsigned bo = xin ? (unsigned)(((((size_t)(dn[i] - n0) * p.H + hi) * p.W + wi_) * p.Cin + ci0 + ch * 8) * 2) : OOB;
+            unsigned char *dst = smem + buf * STAGE + piece * 1024;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rzh, (lds_ptr_t)dst, 16, (int)ao, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rzl, (lds_ptr_t)(dst + PLANE), 16, (int)ao, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_ptr_t)(dst + 2 * PLANE), 16, (int)bo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_ptr_t)(dst + 3 * PLANE), 16, (int)bo, 0, 0, 0);
+            dwo[i] += adv_w;
+            dho[i] += adv_h;
+            if (dwo[i] >= p.Wo) {
+                dwo[i] -= p.Wo;
+                ++dho[i];
+            }
+            while (dho[i] >= p.Ho) {
+                dho[i] -= p.Ho;
+                ++dn[i];
+            }
+        }
+    };
+
     const int steps = (r_end - r_begin + KS - 1) / KS;
     if (steps > 0) {
-        load_step(r_begin);
-        store_step(0);
+        if constexpr (DMA) {
+            issue_step(r_begin, 0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            load_step(r_begin);
+            store_step(0);
+        }
     }
     __syncthreads();
     for (int s = 0; s < steps; ++s) {
         const int buf = s & 1;
-        if (s + 1 < steps) load_step(r_begin + (s + 1) * KS);
+        if constexpr (DMA) {
+            if (s + 1 < steps) issue_step(r_begin + (s + 1) * KS, buf ^ 1);   // buf ^ 1 was released by the last barrier
+        } else {
+            if (s + 1 < steps) load_step(r_begin + (s + 1) * KS);
+        }
         const unsigned char *base = smem + buf * STAGE;
         s16x8 ah[NTW], al[NTW], bh[NTW], bl[NTW];
 #pragma unroll
@@ -207,7 +274,11 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
         for (int a = 0; a < NTW; ++a)
 #pragma unroll
             for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah[a]), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
-        if (s + 1 < steps) store_step(buf ^ 1);
+        if constexpr (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the next stage has landed
+        } else {
+            if (s + 1 < steps) store_step(buf ^ 1);
+        }
         __syncthreads();
     }
 
@@ -284,7 +355,11 @@ static int wgrad_b3_run(const float *dz, const float *x, const uint16_t *dz_hi, 
         if (split_in) CER_LAUNCH((conv2d_wgrad_b3_kernel<64, true>), grid, dim3(256), 0, st, a);
         else CER_LAUNCH((conv2d_wgrad_b3_kernel<64, false>), grid, dim3(256), 0, st, a);
     } else {
-        if (split_in) CER_LAUNCH((conv2d_wgrad_b3_kernel<128, true>), grid, dim3(256), 0, st, a);
+        // split planes with whole 16-byte channel chunks: LDS-DMA loader (offsets within a step stay far below 2^31)
+        const bool dma = split_in && (Cout & 7) == 0 && (Cin & 7) == 0 && (long long)(32 + 2ll * H * W) * Cin * 2 < (1ll << 31) &&
+                         32ll * Cout * 2 < (1ll << 31);
+        if (dma) CER_LAUNCH((conv2d_wgrad_b3_kernel<128, true, true>), grid, dim3(256), 0, st, a);
+        else if (split_in) CER_LAUNCH((conv2d_wgrad_b3_kernel<128, true>), grid, dim3(256), 0, st, a);
         else CER_LAUNCH((conv2d_wgrad_b3_kernel<128, false>), grid, dim3(256), 0, st, a);
     }
     if (splits > 1)
