@@ -107,3 +107,38 @@ def test_frozen_bn_mode_keeps_eval_behaviour_under_train():
         emb = vb(frames.cuda()).cpu()
         ref = oracle.ir50_forward(frames, vsd, "backbone.")
     assert (emb - ref).abs().max().item() < EMB_TOL
+
+
+@pytest.mark.parametrize("precision,tile,tol", [("bf16x3", 52, 2e-5), ("fp16", 82, 2e-3)])
+@pytest.mark.parametrize("train", [False, True])
+def test_space_to_depth_hand_over_is_a_drop_in_for_the_flat_stride2_path(precision, tile, tol, train):
+    """The stride-2 units hand their intermediate over space-to-depth (csrc/conv_b3_s2d.hip / conv_n16_s2d.hip).  With the
+    hand-over switched off the same forward runs on the flat tap-gather kernel: same products, another summation order."""
+    from feature_vs_text_compound_emotion_amd import ops, synth
+    from feature_vs_text_compound_emotion_amd.visual_backbone import IR50
+    n, hw = 48, 80
+    vsd = synth.make_state_dict(synth.visual_backbone_spec("", hw // 8), seed=5)
+    frames = torch.randn(n, 3, hw, hw, generator=torch.Generator().manual_seed(9)).cuda()
+
+    def run(s2d):
+        vb = _build(vsd, hw // 8, precision)
+        if train:
+            vb.train()
+        saved = IR50._s2d_pair_ok
+        if not s2d:
+            IR50._s2d_pair_ok = classmethod(lambda cls, *a, **k: False)
+        ops.CONV_TRACE = []
+        try:
+            with torch.no_grad():
+                mask = torch.ones(n, hw // 8, hw // 8, 512, device="cuda") if train else None
+                emb = vb(frames, mask) if train else vb(frames)
+            tiles = [t[0] for t in ops.CONV_TRACE]
+        finally:
+            ops.CONV_TRACE = None
+            IR50._s2d_pair_ok = saved
+        return emb.float().cpu(), tiles
+
+    on, tiles_on = run(True)
+    off, tiles_off = run(False)
+    assert tile in tiles_on and tile not in tiles_off          # the window-resident stride-2 kernel really ran
+    assert (on - off).abs().max().item() < tol
