@@ -65,7 +65,9 @@ class ClipDataParallel:
         # starts dropout_seed at 0 -- fold the rank in (2^20 steps apart)
         if self.world > 1 and dist.is_initialized() and hasattr(model, "dropout_seed"):
             model.dropout_seed += dist.get_rank() << 20
-        self.overlap = bool(overlap) and self.world > 1 and dist.is_initialized()
+        # ``overlap="force"`` keeps the hook-driven slices on with ONE rank too (a single-rank RCCL communicator is legal):
+        # the path the first multi-GPU run will take, exercised on one GPU (tests/test_rccl_single_rank_gpu.py)
+        self.overlap = bool(overlap) and dist.is_initialized() and (self.world > 1 or overlap == "force")
         self.buckets, self._works = [], []
         if self.overlap:
             self._build_buckets(bucket_mb)
@@ -86,15 +88,25 @@ class ClipDataParallel:
         self.buckets.append([start, off, count])
         self._pending = [b[2] for b in self.buckets]
         self._launched = [False] * len(self.buckets)
+        self._next = len(self.buckets) - 1
         for p, b in zip(self.params, index_of):
             p.register_post_accumulate_grad_hook(self._make_hook(b))
 
     def _make_hook(self, b):
         def hook(_param):
             self._pending[b] -= 1
-            if self._pending[b] == 0 and not self._launched[b]:
-                self._launch(b)
+            self._launch_ready()
         return hook
+
+    def _launch_ready(self):
+        """Collectives are issued STRICTLY in reverse slice order (last slice first, what a top-down backward completes
+        first anyway): slice b goes out only when every slice above it has.  The issue order is then the same on every rank
+        even when a parameter gets no gradient on one of them (a data-dependent branch, a modality absent from a shard) --
+        that rank's slice, and everything below it, simply waits for ``all_reduce_gradients`` -- instead of following each
+        rank's own autograd firing order, which would pair differently sized collectives across ranks."""
+        while self._next >= 0 and self._pending[self._next] == 0:
+            self._launch(self._next)
+            self._next -= 1
 
     def _launch(self, b):
         s, e, _ = self.buckets[b]
@@ -145,6 +157,7 @@ class ClipDataParallel:
         if self.overlap:
             self._pending = [b[2] for b in self.buckets]
             self._launched = [False] * len(self.buckets)
+            self._next = len(self.buckets) - 1
             self._works = []
         off = 0
         for p in self.params:
@@ -154,11 +167,11 @@ class ClipDataParallel:
 
     def all_reduce_gradients(self):
         """Mean of the gradients over ranks, in place in the bucket."""
-        if self.world > 1:
+        if self.world > 1 or self.overlap:
             if self.overlap:
-                for b in range(len(self.buckets)):   # slices whose parameters got no gradient this step (still zeros)
-                    if not self._launched[b]:
-                        self._launch(b)
+                while self._next >= 0:   # slices at / below one whose parameters got no gradient this step, same order
+                    self._launch(self._next)
+                    self._next -= 1
                 for w in self._works:
                     w.wait()
                 self._works = []

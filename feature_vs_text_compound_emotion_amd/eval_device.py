@@ -16,7 +16,14 @@ from .metrics import (CFUSE_MATRIX, CL_ACC, FRAME_LEVEL, FRM_AVG_LOGITS, FRM_AVG
 
 def stitch_windows(win_out, starts, total):
     """win_out [nw, Lw, C] (GPU), starts: list of window start frames -> [total, C]; trainer.py:832-892 in one launch."""
+    if not (isinstance(win_out, torch.Tensor) and win_out.is_cuda and win_out.dtype == torch.float32 and win_out.dim() == 3):
+        raise ValueError("stitch_windows: expected a [n_windows, window_length, n_classes] float32 GPU tensor")
     nw, lw, c = win_out.shape
+    starts = [int(s) for s in starts]
+    if len(starts) != nw:
+        raise ValueError(f"stitch_windows: {nw} windows but {len(starts)} start frames (one video per call)")
+    if nw and (min(starts) < 0 or max(starts) + lw > total):
+        raise ValueError(f"stitch_windows: a window of {lw} frames starting at {max(starts)} leaves the {total}-frame video")
     st = torch.tensor(list(starts), dtype=torch.int32, device=win_out.device)
     out = torch.empty((total, c), device=win_out.device, dtype=torch.float32)
     check(_lib.load().cer_window_stitch(ptr(win_out.contiguous()), ptr(st), nw, lw, c, total, ptr(out), current_stream()),
@@ -55,6 +62,8 @@ class DeviceEvalAccumulator:
         videos are concatenated (default: one video)."""
         if not (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.shape[1] == self.c):
             raise ValueError("logits: expected a [R, n_classes] float32 GPU tensor")
+        if not (isinstance(labels, torch.Tensor) and labels.is_cuda):
+            raise ValueError("labels: expected a GPU tensor (one label per logits row)")
         logits = logits.contiguous()
         labels = labels.reshape(-1).float().contiguous()
         r = logits.shape[0]

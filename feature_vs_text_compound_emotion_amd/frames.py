@@ -70,14 +70,16 @@ class FrameTransform:
             self._tables[key] = (dev, hk.shape[1], vk.shape[1], span)
         return self._tables[key]
 
-    def draw(self, n_clips):
-        """(x1, y1, flip) per clip -- the reference's random calls, in its order."""
+    def draw(self, n_clips, rng=None):
+        """(x1, y1, flip) per clip -- the reference's random calls, in its order.  ``rng``: a ``random.Random`` instance to
+        draw from (the prefetcher's own stream); default the global ``random`` module the reference uses."""
+        rng = random if rng is None else rng
         out = np.zeros((n_clips, 3), np.int32)
         for i in range(n_clips):
             if self.train:
-                out[i, 0] = random.randint(0, self.size - self.crop)
-                out[i, 1] = random.randint(0, self.size - self.crop)
-                out[i, 2] = 1 if random.random() < 0.5 else 0
+                out[i, 0] = rng.randint(0, self.size - self.crop)
+                out[i, 1] = rng.randint(0, self.size - self.crop)
+                out[i, 2] = 1 if rng.random() < 0.5 else 0
             else:
                 out[i, 0] = out[i, 1] = int(round((self.size - self.crop) / 2.0))
         return out

@@ -16,6 +16,7 @@ completed (event), so the model never sees a buffer that is being refilled.  uin
 smaller (19 KB per 40x40 frame), but producing them costs the reference ~0.8 ms of PIL work per frame and process.
 """
 import queue
+import random
 import threading
 from concurrent.futures import ThreadPoolExecutor
 
@@ -27,10 +28,13 @@ class DevicePrefetcher:
     """Iterate ``(inputs, trials, lengths, indices)`` batches of a ``TrialDataset``-like dataset, resident on ``device``.
 
     ``batches``: list of index lists (the sampler's output for one epoch).  ``frame_transform``: a ``FrameTransform`` (its
-    crop / flip draws are made here, in batch order, from Python's ``random`` like the reference's transforms) or None.
+    crop / flip draws are made here, in batch order) or None.  The draws come from the prefetcher's OWN ``random.Random``
+    stream, seeded at construction on the caller's thread from Python's global generator (``seed`` overrides): the producer
+    thread runs ``depth`` batches ahead of the main thread, so drawing from the shared global stream would interleave with
+    the main thread's own uses of ``random`` in a timing-dependent order and a seeded run would not reproduce its crops.
     """
 
-    def __init__(self, dataset, batches, device="cuda", frame_transform=None, num_workers=6, depth=2):
+    def __init__(self, dataset, batches, device="cuda", frame_transform=None, num_workers=6, depth=2, seed=None):
         if not torch.cuda.is_available():
             raise RuntimeError("DevicePrefetcher stages batches for the GPU path: no CUDA/HIP device")
         dev = torch.device(device)
@@ -46,6 +50,7 @@ class DevicePrefetcher:
             self.free.put({"id": s, "pinned": {}, "released": None})
         self.error = None
         self._last = None
+        self.rng = random.Random(random.getrandbits(64) if seed is None else seed)
         self.thread = threading.Thread(target=self._produce, daemon=True)
         self.thread.start()
 
@@ -76,7 +81,7 @@ class DevicePrefetcher:
                     slot["released"].synchronize()           # the previous transfer out of this slot has completed
                 items = list(self.pool.map(self.dataset.__getitem__, idxs))
                 examples = [it[0] for it in items]
-                crop = self.transform.draw(len(items)) if (self.transform is not None and "video" in examples[0]) else None
+                crop = self.transform.draw(len(items), self.rng) if (self.transform is not None and "video" in examples[0]) else None
                 out = {}
                 with torch.cuda.stream(self.stream):
                     for k in examples[0]:

@@ -295,9 +295,22 @@ def make_state_dict(spec, alias=None, seed=0):
     return sd
 
 
-def lfan_state_dict(modalities, n_cls=7, head_hw=5, seed=0):
+def lfan_state_dict(modalities, n_cls=7, head_hw=5, seed=0, conditioned=False):
+    """``conditioned``: the same draw with the biases of the VIDEO temporal net scaled by 0.1.  The default draw gives the
+    TCN biases N(0, 0.1) against a signal of ~0.03 (unit-norm 512-d embeddings through weight-normed filters), so about
+    half of its LeakyReLU channels are switched off for every frame and a few sit right at the switch: one pre-activation
+    changing sign under a 1e-3 relative perturbation of the embeddings multiplies that element's gradient by 100 (slope
+    0.01 -> 1) behind a batch-statistics BatchNorm1d whose gain on an almost constant channel is 1 / sqrt(eps) = 316, and
+    the tail's gradient moves by tens of percent (tests/test_conditioning_cpu.py shows it on the CPU oracle alone).  With
+    the biases at the scale of the signal the channels carry mixed signs and the same perturbation moves the gradient by
+    a few percent -- the well-conditioned problem on which update-level comparisons between precisions are meaningful."""
     spec, alias = lfan_spec(modalities, n_cls=n_cls, head_hw=head_hw)
-    return make_state_dict(spec, alias, seed)
+    sd = make_state_dict(spec, alias, seed)
+    if conditioned:
+        for k, v in sd.items():
+            if k.startswith("temporal.video.") and k.endswith(".bias") and k not in alias:
+                v.mul_(0.1)
+    return sd
 
 
 def make_clip_batch(modalities, batch, length, hw=40, seed=1234, n_cls=7):

@@ -44,43 +44,80 @@ class _Flatten(nn.Module):
     pass
 
 
-def _conv_prec(x, wp, kh, kw, stride, pad, prec):
+def _conv_prec(x, wp, kh, kw, stride, pad, prec, out_hw=None):
     """Dense NHWC fp32 in / out; the arithmetic of the encoder's precision mode: "bf16x3" (split operands, three MFMAs per
     product, <= 2^-15 relative per product), narrow storage ("bf16" / "fp16": operands rounded once, one MFMA), or the exact
     fp32 kernels.  Used by the released units' forward and data-gradient convs (the reference runs them in the same
     arithmetic as the rest of the encoder: fp32, or fp16 under --amp autocast)."""
     if prec == "bf16x3":   # x may be a Split already (the released units keep their conv inputs split for the weight gradient)
         xs = x if isinstance(x, ops.Split) else ops.split_bf16(x)
-        return ops.conv2d_b3(xs, ops.split_bf16(wp), kh, kw, stride=stride, pad=pad, out_f32=True, out_split=False)["y"]
+        return ops.conv2d_b3(xs, ops.split_bf16(wp), kh, kw, stride=stride, pad=pad, out_hw=out_hw, out_f32=True,
+                             out_split=False)["y"]
+    if isinstance(x, ops.Split):
+        x = x.float()
     if prec in ("bf16", "fp16"):
         dt = torch.bfloat16 if prec == "bf16" else torch.float16
-        return ops.conv2d_n16(ops.to_n16(x, dt), ops.to_n16(wp, dt), kh, kw, stride=stride, pad=pad, out_f32=True,
+        return ops.conv2d_n16(ops.to_n16(x, dt), ops.to_n16(wp, dt), kh, kw, stride=stride, pad=pad, out_hw=out_hw, out_f32=True,
                               out_n16=False)["y"]
-    return ops.conv2d(x, wp, kh, kw, stride=stride, pad=pad)
+    return ops.conv2d(x, wp, kh, kw, stride=stride, pad=pad, out_hw=out_hw)
+
+
+# stride-2 data gradient, per dimension (k = 3, pad 1: y[o] = sum_k x[2o + k - 1] w[k]; k = 1, pad 0: y[o] = x[2o] w[0]):
+#   dx[2j]     = dy[j] w[1]                       -> input parity 0: one tap, at dy offset 0
+#   dx[2j + 1] = dy[j] w[2] + dy[j + 1] w[0]      -> input parity 1: two taps, at dy offsets (0, 1)
+_S2_TAPS = {3: ([1], [2, 0]), 1: ([0], [])}
 
 
 def _conv_dgrad(dy, w_oihw, stride, pad, in_hw, prec="fp32"):
-    """Data gradient of a conv (fp32 kernels): the forward kernel on the transposed + flipped filter with padding
-    k-1-pad; for stride > 1 the output gradient is first spread onto the stride grid of a zero image sized so that this
-    is a NATURAL convolution geometry (H_up + 2(k-1-pad) - k + 1 == H_in)."""
+    """Data gradient of a conv in the encoder's arithmetic.  Stride 1: the forward kernel on the transposed + flipped filter
+    with padding k-1-pad.  Stride 2 (the 3x3 / pad 1 second conv and the 1x1 shortcut of the first unit of a stage,
+    arcface_model.py:38-41,46-52): the four input-pixel parities are four stride-1 convs of dy with the filter taps that can
+    reach them -- 1x1, 1x2, 2x1 and 2x2 taps for a 3x3 filter (the decomposition conv_b3_s2d.hip runs forward), 9 tap-MACs
+    per output pixel of dy like the forward conv, instead of a stride-1 conv over dy spread onto a 4x larger zero image (36)."""
     kh, kw = w_oihw.shape[2], w_oihw.shape[3]
-    wt = ops.pack_conv_weight(w_oihw.contiguous(), flip=True, transpose=True)
     n, ho, wo, c = dy.shape
-    hu, wu = in_hw[0] - kh + 1 + 2 * pad, in_hw[1] - kw + 1 + 2 * pad
-    if stride > 1 or (hu, wu) != (ho, wo):
-        if isinstance(dy, ops.Split):
-            dy = dy.float()
-        up = torch.zeros((n, hu, wu, c), device=dy.device, dtype=dy.dtype)
-        up[:, :(ho - 1) * stride + 1:stride, :(wo - 1) * stride + 1:stride] = dy
-        dy = up
-    return _conv_prec(dy, wt, kh, kw, 1, (kh - 1 - pad, kw - 1 - pad), prec)
+    if stride == 1:
+        if (in_hw[0] - kh + 1 + 2 * pad, in_hw[1] - kw + 1 + 2 * pad) != (ho, wo):
+            raise ValueError("stride-1 data gradient: dy does not have the conv's output geometry")
+        wt = ops.pack_conv_weight(w_oihw.contiguous(), flip=True, transpose=True)
+        return _conv_prec(dy, wt, kh, kw, 1, (kh - 1 - pad, kw - 1 - pad), prec)
+    if stride != 2 or kh != kw or kh not in _S2_TAPS or pad != kh // 2:
+        raise NotImplementedError("data gradient: stride 1, or stride 2 with a 3x3 / pad 1 or 1x1 / pad 0 filter (the IR-50 set)")
+    hin, win = in_hw
+    if ((hin + 2 * pad - kh) // 2 + 1, (win + 2 * pad - kw) // 2 + 1) != (ho, wo):
+        raise ValueError("stride-2 data gradient: dy does not have the conv's output geometry")
+    cin = w_oihw.shape[1]
+    dev = dy.hi.device if isinstance(dy, ops.Split) else dy.device
+    taps = _S2_TAPS[kh]
+    dx = (torch.empty if kh == 3 else torch.zeros)((n, hin, win, cin), device=dev, dtype=torch.float32)
+    for py in (0, 1):
+        for px in (0, 1):
+            th, tw = taps[py], taps[px]
+            hp, wq = (hin - py + 1) // 2, (win - px + 1) // 2
+            if not th or not tw or hp == 0 or wq == 0:
+                continue
+            sub = w_oihw[:, :, th][:, :, :, tw].contiguous()                      # [Cout, Cin, len(th), len(tw)]
+            wt = ops.pack_conv_weight(sub, flip=False, transpose=True)
+            dx[:, py::2, px::2] = _conv_prec(dy, wt, len(th), len(tw), 1, (0, 0), prec, out_hw=(hp, wq))
+    return dx
+
+
+def _bn_affine_from_saved(save_mean, save_invstd, gamma, beta):
+    scale = save_invstd * gamma
+    return scale.contiguous(), (beta - save_mean * scale).contiguous()
 
 
 class _ReleasedUnit(torch.autograd.Function):
     """One bottleneck_IR unit (arcface_model.py:44-60) in train mode WITH its backward, for the body groups of the
-    reference's gradual release (base/parameter_control.py:55-103: stage 4, then half of stage 3).  Exact-fp32 kernels:
-    row BatchNorm fwd/bwd, implicit-GEMM conv (forward and, on the transposed/flipped filter, data gradient), the 2-D
-    TN weight-gradient GEMM, PReLU fwd/bwd."""
+    reference's gradual release (base/parameter_control.py:55-103: stage 4, then half of stage 3) and, as an extension, the
+    whole body (BASELINE configs[1]).  Row BatchNorm fwd/bwd, convs (forward and data gradient) in the encoder's precision
+    mode, the matrix-core weight-gradient kernel, PReLU fwd/bwd.
+
+    Activation memory: only the RAW tensors are kept for the backward -- the unit input ``x`` (the previous unit's output,
+    kept anyway), the two raw conv results ``z1`` / ``z2`` (and the raw shortcut conv ``zs``), 12-16 bytes per unit element
+    -- and the two conv INPUTS are recomputed there: ``BN1(x)`` from the saved batch statistics (one fused affine + split
+    pass) and ``PReLU(z1)``.  Round 2 also kept both conv inputs as split tensors (+8 bytes per element: 218 -> 131 MB per
+    224x224 frame over the whole encoder), which is what stopped B = 32 x 32 frames from fitting the 288 GB."""
 
     @staticmethod
     def forward(ctx, x, u, prec, g1, b1, w1, a1, w2, g2, b2, ws, gs, bs):
@@ -90,13 +127,15 @@ class _ReleasedUnit(torch.autograd.Function):
                                        bn1.eps, bn1.momentum)
         xb = xb.view(n, h, w, cin)
         b3 = prec == "bf16x3"
-        # bf16x3: the conv inputs are split once and kept split for the weight-gradient kernel (same bytes as fp32)
         xb_k = ops.split_bf16(xb) if b3 else xb
+        del xb
         z1 = _conv_prec(xb_k, ops.pack_conv_weight(w1.detach().contiguous()), 3, 3, 1, (1, 1), prec)
+        del xb_k
         t1 = ops.prelu_fwd(z1, a1.detach().contiguous())
         t1_k = ops.split_bf16(t1) if b3 else t1
+        del t1
         z2 = _conv_prec(t1_k, ops.pack_conv_weight(w2.detach().contiguous()), 3, 3, s, (1, 1), prec)
-        del xb, t1
+        del t1_k
         _, ho, wo, depth = z2.shape
         out, sm2, si2 = ops.bn_rows_fwd(z2.view(-1, depth), g2.detach(), b2.detach(), bn2.running_mean, bn2.running_var, True,
                                         bn2.eps, bn2.momentum)
@@ -110,8 +149,7 @@ class _ReleasedUnit(torch.autograd.Function):
             ops.add_inplace(out, sc.view(n, ho, wo, depth))
         else:
             ops.add_inplace(out, x[:, ::s, ::s].contiguous() if s > 1 else x)  # MaxPool2d(1, s) == subsample
-        ctx.save_for_backward(x, xb_k.hi if b3 else xb_k, xb_k.lo if b3 else None, z1, t1_k.hi if b3 else t1_k,
-                              t1_k.lo if b3 else None, z2, sm1, si1, sm2, si2, zs, sms, sis, g1.detach(), w1.detach(),
+        ctx.save_for_backward(x, z1, z2, sm1, si1, sm2, si2, zs, sms, sis, g1.detach(), b1.detach(), w1.detach(),
                               a1.detach(), w2.detach(), g2.detach(), ws.detach() if ws is not None else None,
                               gs.detach() if gs is not None else None)
         ctx.stride = s
@@ -120,27 +158,44 @@ class _ReleasedUnit(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
-        x, xb, xb_lo, z1, t1, t1_lo, z2, sm1, si1, sm2, si2, zs, sms, sis, g1, w1, a1, w2, g2, ws, gs = ctx.saved_tensors
+        x, z1, z2, sm1, si1, sm2, si2, zs, sms, sis, g1, b1, w1, a1, w2, g2, ws, gs = ctx.saved_tensors
         s, prec = ctx.stride, ctx.prec
+        # fp16 storage has no range for UN-scaled gradients: a mean cross-entropy gradient divided over B*L rows and H*W
+        # pixels sits at or below fp16's smallest subnormal (6e-8) and would flush to zero when the output gradient is
+        # rounded to the storage type.  The reference always pairs fp16 with GradScaler (trainer.py:341,389); this package's
+        # own Trainer has no scaler, so the data-gradient convs of an fp16 encoder run on the bf16x3 kernels (fp32 range,
+        # 2^-15 per product) -- scaled or not, nothing underflows.
+        dprec = "bf16x3" if prec == "fp16" else prec
         n, h, w, cin = x.shape
         _, ho, wo, depth = z2.shape
         dout = dout.contiguous()
         dz2, dg2, db2 = ops.bn_rows_bwd(dout.view(-1, depth), z2.view(-1, depth), sm2, si2, g2)
         dz2 = dz2.view(n, ho, wo, depth)
         b3 = prec != "fp32"   # the weight gradients follow the convs onto the bf16x3 matrix-core kernel
-        split = xb_lo is not None   # bf16x3: operands stay split (one conversion per tensor, shared by wgrad and dgrad)
+        split = prec == "bf16x3"   # operands split once per tensor, shared by the weight and the data gradient
+        t1 = ops.prelu_fwd(z1, a1.contiguous())                 # recomputed conv input (see the class docstring)
         if split:
-            xb, t1 = ops.Split(xb, xb_lo), ops.Split(t1, t1_lo)
+            t1 = ops.split_bf16(t1)
             dz2 = ops.split_bf16(dz2)
         dw2 = ops.conv2d_wgrad(dz2, t1, 3, 3, stride=s, pad=(1, 1), b3=b3)
-        dt1 = _conv_dgrad(dz2, w2, s, 1, (h, w), prec)
+        del t1
+        dt1 = _conv_dgrad(dz2, w2, s, 1, (h, w), dprec)
+        del dz2
         dz1, da1 = ops.prelu_bwd(dt1, z1, a1.contiguous())
+        del dt1
+        sc1, sh1 = _bn_affine_from_saved(sm1, si1, g1, b1)
         if split:
             dz1 = ops.split_bf16(dz1)
+            xb = ops.split_bf16(x, sc1, sh1)                    # BN1(x) recomputed and split in one pass
+        else:
+            xb = torch.addcmul(sh1, x, sc1)
         dw1 = ops.conv2d_wgrad(dz1, xb, 3, 3, stride=1, pad=(1, 1), b3=b3)
+        del xb
         need_dx = ctx.needs_input_grad[0]
-        dxb = _conv_dgrad(dz1, w1, 1, 1, (h, w), prec)
+        dxb = _conv_dgrad(dz1, w1, 1, 1, (h, w), dprec)
+        del dz1
         dx, dg1, db1 = ops.bn_rows_bwd(dxb.view(-1, cin), x.view(-1, cin), sm1, si1, g1)
+        del dxb
         dx = dx.view(n, h, w, cin)
         dws = dgs = dbs = None
         if ws is not None:
@@ -150,7 +205,11 @@ class _ReleasedUnit(torch.autograd.Function):
                 dzs = ops.split_bf16(dzs)
             dws = ops.conv2d_wgrad(dzs, x, 1, 1, stride=s, pad=(0, 0), b3=b3)
             if need_dx:
-                ops.add_inplace(dx, _conv_dgrad(dzs, ws, s, 0, (h, w), prec))
+                if s == 1:
+                    ops.add_inplace(dx, _conv_dgrad(dzs, ws, 1, 0, (h, w), dprec))
+                else:   # a 1x1 / stride-2 conv only reaches the even input pixels
+                    wt = ops.pack_conv_weight(ws.contiguous(), flip=False, transpose=True)
+                    dx[:, ::2, ::2] += _conv_prec(dzs, wt, 1, 1, 1, (0, 0), dprec)
         elif need_dx:
             if s > 1:
                 dx[:, ::s, ::s] += dout
@@ -163,7 +222,8 @@ class _ReleasedStem(torch.autograd.Function):
     """``input_layer`` (Conv2d(3, 64, 3, 1, 1, bias=False) -> BatchNorm2d -> PReLU, arcface_model.py:130-132) in train mode with
     its backward: the last piece of a backward through the WHOLE encoder (BASELINE configs[1]; the reference's own release
     schedule stops at half of stage 3).  The conv is the NCHW-reading fp32 kernel; its weight gradient runs on the bf16x3
-    matrix-core kernel over a 4-channel NHWC copy of the frames (no data gradient: the frames need none)."""
+    matrix-core kernel over a 4-channel NHWC copy of the frames (no data gradient: the frames need none).  Only the raw conv
+    result is kept for the backward; the BatchNorm output the PReLU saw is recomputed from the saved statistics."""
 
     @staticmethod
     def forward(ctx, x, bn, w, g, b, a):
@@ -171,17 +231,20 @@ class _ReleasedStem(torch.autograd.Function):
         z = ops.conv2d(x.contiguous(), ops.pack_conv_weight(w.detach().contiguous()), 3, 3, pad=(1, 1), x_nchw=True)
         zb, sm, si = ops.bn_rows_fwd(z.view(-1, 64), g.detach(), b.detach(), bn.running_mean, bn.running_var, True, bn.eps,
                                      bn.momentum)
-        zb = zb.view(n, h, wd, 64)
-        y = ops.prelu_fwd(zb, a.detach().contiguous())
-        ctx.save_for_backward(x, z, zb, sm, si, g.detach(), a.detach())
+        y = ops.prelu_fwd(zb.view(n, h, wd, 64), a.detach().contiguous())
+        ctx.save_for_backward(x, z, sm, si, g.detach(), b.detach(), a.detach())
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        x, z, zb, sm, si, g, a = ctx.saved_tensors
+        x, z, sm, si, g, b, a = ctx.saved_tensors
         n, _, h, wd = x.shape
+        sc, sh = _bn_affine_from_saved(sm, si, g, b)
+        zb = torch.addcmul(sh, z, sc)
         dzb, da = ops.prelu_bwd(dy.contiguous(), zb, a.contiguous())
+        del zb
         dz, dg, db = ops.bn_rows_bwd(dzb.view(-1, 64), z.view(-1, 64), sm, si, g)
+        del dzb
         x4 = torch.zeros((n, h, wd, 4), device=x.device, dtype=torch.float32)
         x4[..., :3] = x.permute(0, 2, 3, 1)
         dw = ops.conv2d_wgrad(dz.view(n, h, wd, 64), x4, 3, 3, stride=1, pad=(1, 1), b3=True)[:, :3].contiguous()

@@ -24,10 +24,10 @@ def _free_port():
     return p
 
 
-def _model(seed=0):
+def _model(seed=0, conditioned=False):
     from feature_vs_text_compound_emotion_amd import synth
     from feature_vs_text_compound_emotion_amd.lfan import LFAN
-    sd = synth.lfan_state_dict(MODS, n_cls=7, head_hw=HW // 8, seed=seed)
+    sd = synth.lfan_state_dict(MODS, n_cls=7, head_hw=HW // 8, seed=seed, conditioned=conditioned)
     model = LFAN(backbone_settings={}, output_dim=7, task="CLASSIFICATION", modality=MODS, example_length=L, kernel_size=5,
                  tcn_channel=synth.TCN_CHANNELS, root_dir="", device="cuda", head_hw=HW // 8)
     model.init(load_backbone=False)
@@ -136,16 +136,25 @@ def _flat_trainable(model):
     return torch.cat([p.detach().reshape(-1) for p in model.parameters() if p.requires_grad]).cpu()
 
 
-def test_reference_amp_wrapper_drives_the_hip_model():
+@pytest.mark.parametrize("conditioned", [True, False])
+def test_reference_amp_wrapper_drives_the_hip_model(conditioned):
     """Under autocast the encoder follows the reference onto fp16 arithmetic (narrow kernels); GradScaler's loss scaling
     passes through the hand-written backward (a power of two: exact) and the step equals the un-scaled step of the same
-    model pinned to precision = "fp16"."""
+    model pinned to precision = "fp16".
+
+    fp16 storage against the 2^-15-per-product encoder: on the well-conditioned problem (``conditioned=True``: video-TCN
+    biases at the scale of the signal, synth.lfan_state_dict) the two-step parameter UPDATE agrees to < 10 % (storage-only
+    emulation on the CPU: 2.5 %).  On the default draw this batch seed sits on a LeakyReLU switch of the video temporal net
+    and the same 2e-3 relative embedding difference moves the update by ~40 % -- reproduced WITHOUT any kernel by
+    tests/test_conditioning_cpu.py (storage-only emulation: 0.43; another batch seed, same weights: 0.009), so for that
+    case the update is bounded by the emulation's value instead (it is a property of the problem, and it is the fp32
+    reference's sensitivity too)."""
     from feature_vs_text_compound_emotion_amd import synth
     x, labels = synth.make_clip_batch(MODS, B, L, hw=HW, seed=56)
     xd, ld = {k: v.cuda() for k, v in x.items()}, labels.cuda()
 
     def fresh(precision):
-        m = _model()
+        m = _model(conditioned=conditioned)
         m.spatial["visual"].backbone.precision = precision
         for mod in m.modules():                 # same dropout-free step on both sides
             if isinstance(mod, torch.nn.Dropout):
@@ -157,17 +166,12 @@ def test_reference_amp_wrapper_drives_the_hip_model():
     l_amp, w_amp = _reference_amp_steps(fresh("bf16x3"), xd, ld, amp=True)      # autocast switches the encoder to fp16
     l_f16, w_f16 = _reference_amp_steps(fresh("fp16"), xd, ld, amp=False)       # the same arithmetic without the wrapper
     l_ref, w_ref = _reference_amp_steps(fresh("bf16x3"), xd, ld, amp=False)     # full-precision step
-    print(f"\n[amp] losses amp {l_amp} | fp16 no wrapper {l_f16} | bf16x3 {l_ref}")
+    print(f"\n[amp conditioned={conditioned}] losses amp {l_amp} | fp16 no wrapper {l_f16} | bf16x3 {l_ref}")
     assert max(abs(a - b) for a, b in zip(l_amp, l_f16)) < 1e-6
     assert (w_amp - w_f16).abs().max().item() < 1e-7
-    # fp16 storage vs the 2^-15-per-product encoder: the loss moves in the 4th digit.  The parameter UPDATE is not compared
-    # tightly: with 32 random-noise frames the embeddings of different frames are almost equal, so the batch-statistics
-    # BatchNorm1d layers of the tail divide by a tiny spread and turn a 1e-4 embedding difference into sign flips of whole
-    # feature columns (measured: the gradient jumps by a fixed 68 % between 1 % and 10 % of the fp16 perturbation, and is
-    # linear below; in eval mode the same comparison gives 8e-4).  That conditioning belongs to the synthetic batch, not to
-    # the storage type -- the reference's own fp16 autocast run sits on the same cliff.
     upd_amp, upd_ref = w_amp - w_init, w_ref - w_init
     rel = ((upd_amp - upd_ref).norm() / upd_ref.norm()).item()
-    print(f"[amp] relative difference of the two-step update, fp16 autocast vs bf16x3: {rel:.3e} (informational)")
+    print(f"[amp conditioned={conditioned}] relative difference of the two-step update, fp16 autocast vs bf16x3: {rel:.3e}")
+    assert rel < (0.1 if conditioned else 0.6)
     assert max(abs(a - b) for a, b in zip(l_amp, l_ref)) < 5e-3
     assert torch.isfinite(w_amp).all()

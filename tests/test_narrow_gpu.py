@@ -2,11 +2,23 @@
 accumulate) vs the fp32 oracle: BASELINE cfg5 ("bf16 storage / fp32 accumulate", 64-frame clips, C-EXPR-DB classes) and the
 arithmetic of the reference's own --amp recipe (fp16 autocast, trainer.py:341,367).
 
-Bars.  SURVEY section 7 sets cfg5's bar: |logit error| <= 2e-2 and argmax agreement; north_star's 1e-3 is the fp32-parity bar
-(met by precision = "bf16x3" / "fp32", tests/test_backbone_gpu.py, tests/test_tail_gpu.py).  The tests below assert the
-cfg5 bar for both storage types and, for fp16, additionally a 4e-3 bound (measured ~1e-3: its 11-bit mantissa sits right
-at north_star's fp32 bar; bf16's 8-bit mantissa measures ~6e-3 on logits).  Measured values are printed (pytest -s) and
-recorded in DESIGN.md.
+Bars (round 3: every bar states its origin and can fail).
+
+* Like-for-like yardstick: the reference's own narrow arithmetic is torch autocast (trainer.py:367); ``oracle.narrow``
+  runs the fp32 oracle under ``torch.autocast("cpu", dtype)``.  Whole-model LOGITS, eval and train mode: the HIP narrow
+  result has to be closer to the fp32 oracle than that (factor 0.8; measured ~0.15 in eval, ~0.55 in train mode: autocast
+  also narrows the tail, the HIP modes only the encoder).  IR-50 EMBEDDINGS: the encoder is the same arithmetic class as
+  autocast (16-bit tensors, fp32 accumulate; on the CPU the two land within 8 % of each other), so the bar is 1.25 x the
+  yardstick and 1.5 x the storage-only emulation -- two rounding realisations of one format.
+* Absolute: SURVEY section 7's cfg5 bar -- |logit error| <= 2e-2 and argmax agreement -- in eval mode for both storage types,
+  4e-3 for fp16 in BOTH modes (no allowance).  bf16 in ``model.train()``: 3.5e-2.  Not 2e-2, and the reason is demonstrated
+  on the CPU by tests/test_conditioning_cpu.py: train mode normalises the video features by their batch statistics, so the
+  embedding error enters the logits at full weight (eval mode hides it behind synthetic running statistics ~1000x the
+  actual variance); bf16 STORAGE ALONE -- every tensor rounded once, everything else fp32, no kernel involved -- lands at
+  2.2e-2 on this batch and the reference's autocast arithmetic at 5.2e-2.  3.5e-2 = that floor x 1.6 for the spread of a
+  maximum over 1024 logits between two rounding realisations.
+* Embeddings (unit-norm 512-d rows, elements ~0.044): relative L2 and cosine -- an element-wise bound of a few 1e-2 on
+  0.044-sized numbers cannot fail (round-2 verdict) and is gone.
 """
 import pytest
 import torch
@@ -16,8 +28,12 @@ pytestmark = pytest.mark.gpu
 from helpers import MODS  # noqa: E402
 
 DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
-EMB_BAR = {"bf16": 2.5e-2, "fp16": 4e-3}     # unit-norm 512-d embeddings (elements ~0.044)
+EMB_REL = {"bf16": 2.5e-2, "fp16": 3.2e-3}    # relative L2 of the [N,512] embedding matrix (storage-only emulation: 1.7e-2 / 2.1e-3 in train mode)
+EMB_COS = {"bf16": 0.9992, "fp16": 0.99999}   # worst row cosine: 1 - rel^2/2 at twice the relative bar
 LOGIT_BAR = {"bf16": 2e-2, "fp16": 4e-3}
+TRAIN_LOGIT_BAR = {"bf16": 3.5e-2, "fp16": 4e-3}
+YARDSTICK = 0.8          # logits
+YARDSTICK_EMB = 1.25     # embeddings
 
 
 def _vb(sd, head_hw, precision):
@@ -28,30 +44,44 @@ def _vb(sd, head_hw, precision):
     return vb.cuda().eval()
 
 
+def _emb_errors(emb, ref):
+    rel = ((emb - ref).norm() / ref.norm()).item()
+    cos = torch.nn.functional.cosine_similarity(emb, ref, dim=1).min().item()
+    return rel, cos
+
+
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
 @pytest.mark.parametrize("n,hw", [(1, 40), (37, 40), (2, 224), (3, 64)])
 def test_narrow_embedding_vs_oracle(n, hw, precision):
     import oracle
+    from oracle.narrow import autocast_ir50_forward
     from feature_vs_text_compound_emotion_amd import synth
     vsd = synth.make_state_dict(synth.visual_backbone_spec("", hw // 8), seed=11)
     frames = torch.randn(n, 3, hw, hw, generator=torch.Generator().manual_seed(n + hw))
     with torch.no_grad():
         ref = oracle.ir50_forward(frames, vsd, "backbone.")
         emb = _vb(vsd, hw // 8, precision)(frames.cuda()).cpu()
-    err = (emb - ref).abs().max().item()
-    cos = torch.nn.functional.cosine_similarity(emb, ref, dim=1).min().item()
-    print(f"\n[narrow {precision}] IR-50 eval n={n} hw={hw}: max |emb err| {err:.2e}, min cosine {cos:.6f}")
-    assert err < EMB_BAR[precision]
-    assert cos > (0.995 if precision == "bf16" else 0.9999)
+        rel, cos = _emb_errors(emb, ref)
+        msg = f"\n[narrow {precision}] IR-50 eval n={n} hw={hw}: relative L2 {rel:.2e}, min cosine {cos:.6f}"
+        if hw <= 64:      # the autocast oracle at 224x224 costs minutes of CPU bf16 convs; the small shapes carry the yardstick
+            yard, _ = _emb_errors(autocast_ir50_forward(frames, vsd, "backbone.", DT[precision]), ref)
+            msg += f"; reference autocast arithmetic {yard:.2e}"
+            assert rel < YARDSTICK_EMB * yard
+    print(msg)
+    assert rel < EMB_REL[precision]
+    assert cos > EMB_COS[precision]
     assert (emb.norm(dim=1) - 1).abs().max().item() < 1e-5
 
 
 @pytest.mark.parametrize("precision", ["bf16", "fp16"])
-def test_narrow_train_mode_batch_statistics_vs_oracle(precision):
-    """model.train() semantics (batch-statistics BatchNorm in all 54 layers, running buffers updated, injected Dropout mask)."""
+@pytest.mark.parametrize("n", [6, 32])
+def test_narrow_train_mode_batch_statistics_vs_oracle(precision, n):
+    """model.train() semantics (batch-statistics BatchNorm in all 54 layers, running buffers updated, injected Dropout mask)
+    against the fp32 oracle, the reference's autocast arithmetic (yardstick) and the storage-only emulation (the floor)."""
     import oracle
+    from oracle.narrow import autocast_ir50_forward, ir50_forward_narrow_storage
     from feature_vs_text_compound_emotion_amd import synth
-    n, hw = 6, 40
+    hw = 40
     vsd = synth.make_state_dict(synth.visual_backbone_spec("", hw // 8), seed=13)
     g = torch.Generator().manual_seed(n * hw)
     frames = torch.randn(n, 3, hw, hw, generator=g)
@@ -59,15 +89,19 @@ def test_narrow_train_mode_batch_statistics_vs_oracle(precision):
     nb = {}
     with torch.no_grad():
         ref = oracle.ir50_forward(frames, vsd, "backbone.", train=True, head_dropout_mask=mask, new_buffers=nb)
+        yard, _ = _emb_errors(autocast_ir50_forward(frames, vsd, "backbone.", DT[precision], train=True, head_dropout_mask=mask), ref)
+        floor, _ = _emb_errors(ir50_forward_narrow_storage(frames, vsd, "backbone.", DT[precision], head_dropout_mask=mask), ref)
     vb = _vb(vsd, hw // 8, precision).train()
     with torch.no_grad():
         emb = vb(frames.cuda(), mask.permute(0, 2, 3, 1).contiguous().cuda()).cpu()
-    err = (emb - ref).abs().max().item()
+    rel, cos = _emb_errors(emb, ref)
     sd_after = vb.state_dict()
     worst = max(((sd_after[k].cpu() - v).abs() / v.abs().clamp_min(1.0)).max().item() for k, v in nb.items())
-    print(f"\n[narrow {precision}] IR-50 train-mode n={n}: max |emb err| {err:.2e}, worst running-stat rel err {worst:.2e}")
-    # 6 frames: the batch statistics of the deep layers are over 150 values, which amplifies the storage rounding
-    assert err < 2 * EMB_BAR[precision]
+    print(f"\n[narrow {precision}] IR-50 train-mode n={n}: relative L2 {rel:.2e} (storage-only emulation {floor:.2e}, reference "
+          f"autocast arithmetic {yard:.2e}), min cosine {cos:.6f}, worst running-stat rel err {worst:.2e}")
+    assert rel < YARDSTICK_EMB * yard        # as close to fp32 as the reference's own narrow recipe
+    assert rel < 1.5 * floor                 # and at the level 16-bit storage alone costs (two rounding realisations differ)
+    assert rel < EMB_REL[precision] * (2.0 if n == 6 else 1.0)   # 6 frames: statistics of the deep layers over 150 values
     assert worst < (5e-2 if precision == "bf16" else 6e-3)
     assert int(sd_after["backbone.input_layer.1.num_batches_tracked"]) == 1
 
@@ -91,6 +125,7 @@ def test_cfg5_trimodal_64_frame_clips_8_classes(precision):
     from feature_vs_text_compound_emotion_amd import synth
     from feature_vs_text_compound_emotion_amd.lfan import cross_entropy_loss
     from oracle.lfan import cross_entropy_mean, lfan_forward
+    from oracle.narrow import autocast_lfan_forward
     b, length, hw, n_cls = 2, 64, 40, 8
     sd = synth.lfan_state_dict(MODS, n_cls=n_cls, head_hw=hw // 8, seed=0)
     x, labels = synth.make_clip_batch(MODS, b, length, hw=hw, seed=4321, n_cls=n_cls)
@@ -99,6 +134,7 @@ def test_cfg5_trimodal_64_frame_clips_8_classes(precision):
     with torch.no_grad():
         logits = model(dict(xd)).cpu()
         ref = lfan_forward(x, sd, MODS, train=False)
+        yard = (autocast_lfan_forward(x, sd, MODS, DT[precision], train=False) - ref).abs().max().item()
     assert logits.shape == (b, length, n_cls)
     err = (logits - ref).abs().max().item()
     agree = (logits.argmax(-1) == ref.argmax(-1)).float().mean().item()
@@ -107,8 +143,10 @@ def test_cfg5_trimodal_64_frame_clips_8_classes(precision):
     decided = (top2[..., 0] - top2[..., 1]) > 2 * LOGIT_BAR[precision]
     agree_decided = (logits.argmax(-1) == ref.argmax(-1))[decided].float().mean().item() if decided.any() else 1.0
     print(f"\n[narrow {precision}] cfg5 eval: max |logit err| {err:.2e}, argmax agreement {agree:.4f} "
-          f"({agree_decided:.4f} on the {int(decided.sum())} frames with a margin > {2 * LOGIT_BAR[precision]:g})")
+          f"({agree_decided:.4f} on the {int(decided.sum())} frames with a margin > {2 * LOGIT_BAR[precision]:g}); "
+          f"reference autocast arithmetic {yard:.2e}")
     assert err < LOGIT_BAR[precision]
+    assert err < YARDSTICK * yard
     assert agree_decided == 1.0 and agree > 0.97
     # train-mode forward + loss, dropout off (no mask plumbing needed), encoder BatchNorms on batch statistics
     model.train()
@@ -120,10 +158,17 @@ def test_cfg5_trimodal_64_frame_clips_8_classes(precision):
     out = model(dict(xd))
     loss = cross_entropy_loss(out, labels.cuda())
     loss.backward()
-    oref = lfan_forward(x, sd, MODS, train=True, backbone_train=True)
+    with torch.no_grad():
+        oref = lfan_forward(x, sd, MODS, train=True, backbone_train=True)
+        tyard = (autocast_lfan_forward(x, sd, MODS, DT[precision], train=True, backbone_train=True) - oref).abs().max().item()
     oloss = cross_entropy_mean(oref, labels)
-    terr = (out.detach().cpu() - oref).abs().max().item()
-    print(f"[narrow {precision}] cfg5 train forward: max |logit err| {terr:.2e}, loss {loss.item():.6f} vs oracle {oloss.item():.6f}")
-    assert terr < 2 * LOGIT_BAR[precision]
-    assert abs(loss.item() - oloss.item()) < LOGIT_BAR[precision]
+    diff = out.detach().cpu() - oref
+    terr, trms = diff.abs().max().item(), diff.pow(2).mean().sqrt().item()
+    tagree = (out.detach().cpu().argmax(-1) == oref.argmax(-1)).float().mean().item()
+    print(f"[narrow {precision}] cfg5 train forward: max |logit err| {terr:.2e} (rms {trms:.2e}; reference autocast arithmetic "
+          f"{tyard:.2e}), argmax agreement {tagree:.4f}, loss {loss.item():.6f} vs oracle {oloss.item():.6f}")
+    assert terr < TRAIN_LOGIT_BAR[precision]        # module docstring: origin of the bf16 number
+    assert terr < YARDSTICK * tyard
+    assert tagree > 0.95
+    assert abs(loss.item() - oloss.item()) < LOGIT_BAR[precision] / 4
     assert model.regressor.weight.grad is not None and torch.isfinite(model.regressor.weight.grad).all()
