@@ -22,12 +22,14 @@ import torch
 import torch.distributed as dist
 
 
-def init_process_group_from_env(backend=None):
-    """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* come from the launcher (torch.distributed.run)."""
+def init_process_group_from_env(backend=None, single_rank_group=False):
+    """RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* come from the launcher (torch.distributed.run).  ``single_rank_group``:
+    create the process group for WORLD_SIZE == 1 as well (a one-rank RCCL communicator is legal; the tests use it to drive
+    the collectives' stream semantics on one GPU)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or single_rank_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
@@ -128,11 +130,11 @@ class ClipDataParallel:
                     t.copy_(flat[off:off + t.numel()].view_as(t))
                     off += t.numel()
 
-    def sync_buffers(self, mode="mean"):
+    def sync_buffers(self, mode="mean", force=False):
         """BatchNorm running statistics are rank-local during training (each rank == the reference on its shard).  Before
         a checkpoint or an evaluation make them one set again: ``mean`` averages the float buffers over the ranks (every
         shard's statistics count), ``broadcast`` takes rank 0's.  Integer buffers (num_batches_tracked) are equal already."""
-        if self.world == 1:
+        if self.world == 1 and not (force and dist.is_initialized()):   # ``force``: run the collective with one rank too (tests)
             return
         bufs = [b for b in self.model.buffers() if b.dtype == torch.float32]
         if not bufs:

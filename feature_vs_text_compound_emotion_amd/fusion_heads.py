@@ -292,23 +292,34 @@ class _TailModel(nn.Module):
                                                num_channels=tcn_settings[m]["channel"],
                                                kernel_size=tcn_settings[m]["kernel_size"])
             self.bn[m] = nn.BatchNorm1d(tcn_settings[m]["channel"][-1])
-        if "logmel" in modalities:
-            raise NotImplementedError("'logmel' is not an allowed modality in the reference's main.py (parseit.py:329-331)")
         self._front_args = (backbone_settings, root_dir, head_hw, load_backbone)
 
     def _attach_visual(self):
         backbone_settings, root_dir, head_hw, load_backbone = self._front_args
         if "video" in self.modalities:
             self.spatial["visual"] = _load_visual(root_dir, backbone_settings, head_hw, load_backbone)
+        if "logmel" in self.modalities:   # model.py:626-638 / 1120-1132 (dead in main.py; the on-model VGGish)
+            from .audio_backbone import AudioBackbone
+            audio = AudioBackbone()
+            if load_backbone:
+                audio.backbone.load_state_dict(torch.load(join(root_dir, backbone_settings["audio_state_dict"] + ".pth"),
+                                                          map_location="cpu", weights_only=True))
+            self.spatial["audio"] = audio
 
     def _front(self, X):
-        mods = [m for m in X]
-        if mods != self.modalities:
-            raise ValueError(f"input modalities {mods} must match the model's {self.modalities} (same order)")
+        # model.py:651-672 / 1134-1155: the caller's dict is walked in its own key order (any order works: the fusion picks
+        # the modalities by name) and 'video' / 'logmel' are overwritten in place with their embeddings [B, 1, L, C]
+        for m in X:
+            if m not in self.temporal:
+                raise KeyError(m)
+        for m in self.modalities:
+            if m not in X:
+                raise KeyError(m)
         if self.training:
             self.dropout_seed += 1
         feats, bsz, length = {}, None, None
-        for i, m in enumerate(mods):
+        for m in X:
+            i = self.modalities.index(m)               # dropout streams are tied to the model's modality order
             x = X[m]
             if m == "video":
                 bsz, length = x.shape[0], x.shape[1]
@@ -319,6 +330,12 @@ class _TailModel(nn.Module):
                     vis = self.spatial["visual"]
                     vis.backbone.dropout_seed = self.dropout_seed
                     rows = vis(x.reshape(-1, *x.shape[2:]))
+                X[m] = rows.detach().view(bsz, length, -1).unsqueeze(1)
+            elif m == "logmel":
+                bsz, height, length, width = x.shape
+                with torch.no_grad():
+                    rows = self.spatial["audio"](x.permute(0, 2, 3, 1).contiguous().view(-1, width, height))
+                X[m] = rows.view(bsz, length, -1).unsqueeze(1)
             else:
                 bsz, length = x.shape[0], x.shape[2]
                 rows = x.reshape(bsz * length, x.shape[-1])
@@ -391,5 +408,7 @@ class CAN(_TailModel):
 
     def forward(self, X):
         feats, bsz, length = self._front(X)
-        c = self.fuse.forward_rows([feats[m] for m in self.modalities])
+        # model.py:558-560 pairs attn[i] with the i-th VALUE of the caller's dict: the caller's key order is part of the
+        # contract here (another order meets other projection weights, or a shape error), exactly as in the reference
+        c = self.fuse.forward_rows(list(feats.values()))
         return self._head(c, bsz, length)

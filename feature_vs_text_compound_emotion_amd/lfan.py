@@ -21,6 +21,7 @@ from torch import nn
 
 from . import ops
 from .temporal_convnet import TemporalConvNet
+from .audio_backbone import AudioBackbone
 from .visual_backbone import VisualBackbone
 
 CLASSIFICATION, REGRESSION = "CLASSIFICATION", "REGRESSION"  # reference constants.py:17-20
@@ -44,12 +45,13 @@ class LFANHeadFunction(torch.autograd.Function):
 
     args: (meta, buffers, fusion_mask, *tensors) where tensors =
       [t_m for each modality] + per modality [bn_w, bn_b, qkv_w, qkv_b] + [o_w, o_b, ln_w, ln_b, r_w, r_b]
-    meta = (M, H, hd, train); buffers = [(running_mean, running_var)] per modality (updated in place).
+    meta = (M, H, hd, train, sink); buffers = [(running_mean, running_var)] per modality (updated in place); ``sink``: None or a
+    list that receives the M BatchNorm outputs (detached views; what the reference leaves in the caller's dict).
     """
 
     @staticmethod
     def forward(ctx, meta, buffers, fmask, *ts):
-        M, H, hd, train = meta
+        M, H, hd, train, sink = meta
         t = [x.contiguous() for x in ts[:M]]
         per = [ts[M + 4 * i:M + 4 * i + 4] for i in range(M)]
         o_w, o_b, ln_w, ln_b, r_w, r_b = ts[M + 4 * M:]
@@ -70,7 +72,9 @@ class LFANHeadFunction(torch.autograd.Function):
         o = ops.linear(vals, _packed(o_w), bias=o_b)
         _, ln_mean, ln_rstd = ops.layernorm_fwd(o, ln_w, ln_b, mask=fmask, eps=LN_EPS, out=z[:, enc0:])
         logits = ops.linear(z, _packed(r_w), bias=r_b)
-        ctx.meta, ctx.ts = meta, ts
+        if sink is not None:
+            sink.extend(y.detach() for y in ys)
+        ctx.meta, ctx.ts = meta[:4], ts
         ctx.saved = (t, ys, stats, qkvs, vals, probs, o, ln_mean, ln_rstd, z, fmask, enc0)
         return logits
 
@@ -193,6 +197,16 @@ class LFAN(nn.Module):
             param.requires_grad = False
         return resnet
 
+    def load_audio_backbone(self, backbone_settings):
+        """model.py:436-448"""
+        vggish = AudioBackbone()
+        state_dict = torch.load(join(self.root_dir, backbone_settings['audio_state_dict'] + ".pth"), map_location='cpu',
+                                weights_only=True)
+        vggish.backbone.load_state_dict(state_dict)
+        for param in vggish.parameters():
+            param.requires_grad = False
+        return vggish
+
     def init(self, load_backbone=True):
         if 'video' in self.modality:
             if load_backbone:
@@ -201,9 +215,9 @@ class LFAN(nn.Module):
                 self.spatial["visual"] = VisualBackbone(mode='ir', use_pretrained=False, head_hw=self.head_hw)
                 for p in self.spatial["visual"].parameters():
                     p.requires_grad = False
-        if 'logmel' in self.modality:
-            raise NotImplementedError("'logmel' (on-model VGGish) is not an allowed modality in the reference's "
-                                      "main.py (parseit.py:329-331); use the AudioBackbone module directly")
+        if 'logmel' in self.modality:   # model.py:458-461 (dead in the reference's main.py, parseit.py:329-331, but it is the one
+            # place the reference runs VGGish INSIDE forward): weights arrive through load_state_dict / load_audio_backbone
+            self.spatial["audio"] = self.load_audio_backbone(self.backbone_settings) if load_backbone else AudioBackbone()
         for modal in self.modality:
             self.temporal[modal] = TemporalConvNet(num_inputs=self.embedding_dim[modal],
                                                    max_length=self.example_length,
@@ -216,15 +230,22 @@ class LFAN(nn.Module):
         self.regressor = nn.Linear(self.final_dim, self.output_dim)
 
     def forward(self, X):
-        # like the reference, iterate the caller's dict in its own key order (model.py:511)
-        mods = [m for m in X]
-        if mods != self.modality:
-            raise ValueError(f"input modalities {mods} must match the model's {self.modality} (same order)")
+        """model.py:487-526.  Like the reference, the per-modality stage walks the CALLER's dict in its own key order, the
+        fusion walks the model's ``modality`` list, and the caller's dict is overwritten with the per-modality features
+        ([B, L, C_m] after TemporalConvNet + BatchNorm1d, model.py:511-515) -- so the keys may come in any order, and a key
+        the model was not built for (or a missing one) is a KeyError."""
+        for m in X:
+            if m not in self.temporal:
+                raise KeyError(m)                       # self.temporal[modal], model.py:514
+        for m in self.modality:
+            if m not in X:
+                raise KeyError(m)                       # x[modal] in the fusion, transformer.py:137
+        mods = list(self.modality)
         masks = self.test_masks or {}
         if self.training:
             self.dropout_seed += 1
         rows_in, bsz, length = {}, None, None
-        for m in mods:
+        for m in X:
             x = X[m]
             if m == "video":
                 bsz, length = x.shape[0], x.shape[1]
@@ -236,6 +257,11 @@ class LFAN(nn.Module):
                     vis.backbone.dropout_seed = self.dropout_seed
                     emb = vis(x.reshape(-1, *x.shape[2:]), masks.get("head"))
                 rows_in[m] = emb
+            elif m == "logmel":
+                # model.py:500-508: [B, 64 mel bins, L, 96 frames] -> one 96 x 64 example per clip frame -> VGGish
+                bsz, height, length, width = x.shape
+                with torch.no_grad():
+                    rows_in[m] = self.spatial["audio"](x.permute(0, 2, 3, 1).contiguous().view(-1, width, height))
             else:
                 bsz, length = x.shape[0], x.shape[2]
                 rows_in[m] = x.reshape(bsz * length, x.shape[-1])  # [B,1,L,C] -> rows
@@ -261,10 +287,13 @@ class LFAN(nn.Module):
         ts += [attn.o_proj.weight, attn.o_proj.bias, self.fusion.layers.norm1.weight, self.fusion.layers.norm1.bias,
                self.regressor.weight, self.regressor.bias]
         buffers = [(self.bn[m].running_mean, self.bn[m].running_var) for m in mods]
-        logits = LFANHeadFunction.apply((M, H, hd, self.training), buffers, fmask, *ts)
+        sink = []
+        logits = LFANHeadFunction.apply((M, H, hd, self.training, sink), buffers, fmask, *ts)
         if self.training:
             for m in mods:
                 self.bn[m].num_batches_tracked += 1
+        for m, y in zip(mods, sink):                    # the reference's in-place dict updates (model.py:511-515)
+            X[m] = y.view(bsz, length, -1)
         out = logits.view(bsz, self.example_length, -1)
         if self.task == REGRESSION:
             out = torch.tanh(out)

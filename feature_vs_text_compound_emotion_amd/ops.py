@@ -554,6 +554,20 @@ def l2norm_rows(x):
     return y
 
 
+# bench.py sets this to a list to time every matrix-core weight-gradient launch: (Cout, Cin, taps, algorithmic FLOPs, start, end)
+WGRAD_TRACE = None
+
+
+def _wgrad_traced(fn, n, ho, wo, cout, cin, kh, kw):
+    if WGRAD_TRACE is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    WGRAD_TRACE.append((cout, cin, kh * kw, 2.0 * n * ho * wo * cout * cin * kh * kw, e0, e1))
+
+
 def conv2d_wgrad(dz, x, kh, kw, stride=1, pad=(0, 0), b3=False):
     """dW [Cout,Cin,KH,KW] (torch layout) from dz [N,Ho,Wo,Cout] and the conv input x [N,H,W,Cin] (both dense NHWC).
     ``b3``: the bf16x3 MFMA kernel with the pixel range split over blocks (Cout, Cin % 4 == 0; other shapes take the
@@ -571,8 +585,9 @@ def conv2d_wgrad(dz, x, kh, kw, stride=1, pad=(0, 0), b3=False):
         lib = _lib.load()
         nbytes = lib.cer_conv2d_wgrad_b3_workspace_bytes(n, ho, wo, cout, cin, kh, kw)
         ws = torch.empty((nbytes // 4,), device=dw.device, dtype=torch.float32) if nbytes else None
-        check(lib.cer_conv2d_wgrad_b3s(ptr(dz.hi), ptr(dz.lo), ptr(x.hi), ptr(x.lo), ptr(dw), n, h, w, ho, wo, cout, cin, kh, kw,
-                                       stride, pad[0], pad[1], ptr(ws), nbytes, current_stream()), "cer_conv2d_wgrad_b3s")
+        _wgrad_traced(lambda: check(lib.cer_conv2d_wgrad_b3s(ptr(dz.hi), ptr(dz.lo), ptr(x.hi), ptr(x.lo), ptr(dw), n, h, w, ho, wo,
+                                                              cout, cin, kh, kw, stride, pad[0], pad[1], ptr(ws), nbytes,
+                                                              current_stream()), "cer_conv2d_wgrad_b3s"), n, ho, wo, cout, cin, kh, kw)
         return dw
     _dev_f32(dz, "dz")
     _dev_f32(x, "x")
@@ -583,8 +598,9 @@ def conv2d_wgrad(dz, x, kh, kw, stride=1, pad=(0, 0), b3=False):
         lib = _lib.load()
         nbytes = lib.cer_conv2d_wgrad_b3_workspace_bytes(n, ho, wo, cout, cin, kh, kw)
         ws = _empty((nbytes // 4,), dz) if nbytes else None
-        check(lib.cer_conv2d_wgrad_b3(ptr(dz), ptr(x), ptr(dw), n, h, w, ho, wo, cout, cin, kh, kw, stride, pad[0], pad[1],
-                                      ptr(ws), nbytes, current_stream()), "cer_conv2d_wgrad_b3")
+        _wgrad_traced(lambda: check(lib.cer_conv2d_wgrad_b3(ptr(dz), ptr(x), ptr(dw), n, h, w, ho, wo, cout, cin, kh, kw, stride,
+                                                             pad[0], pad[1], ptr(ws), nbytes, current_stream()),
+                                    "cer_conv2d_wgrad_b3"), n, ho, wo, cout, cin, kh, kw)
         return dw
     lib = _lib.load()
     nbytes = lib.cer_conv_wgrad_workspace_bytes(n * ho * wo, cout, cin, kh * kw)

@@ -94,6 +94,8 @@ def lfan_spec(modalities, n_cls=7, head_hw=5, kernel_size=5, modal_dim=32):
         alias.update(a)
     if "video" in modalities:
         s.update(visual_backbone_spec("spatial.visual.", head_hw))
+    if "logmel" in modalities:
+        s.update(vggish_spec("spatial.audio.backbone."))
     for m in modalities:
         _bn_spec(s, f"bn.{m}", TCN_CHANNELS[m][-1])
     for m in modalities:
@@ -322,6 +324,8 @@ def make_clip_batch(modalities, batch, length, hw=40, seed=1234, n_cls=7):
         if m == "video":
             u8 = torch.randint(0, 256, (batch, length, hw, hw, 3), generator=g, dtype=torch.uint8)
             x[m] = ((u8.float() / 255.0 - 0.5) / 0.5).permute(0, 1, 4, 2, 3).contiguous()
+        elif m == "logmel":   # [B, 64 mel bins, L, 96 frames] (model.py:500), values in the range of log(mel + 0.01)
+            x[m] = torch.randn(batch, 64, length, 96, generator=g) * 2.0 - 1.0
         else:
             x[m] = torch.randn(batch, 1, length, EMBEDDING_DIM[m], generator=g)
     cls = torch.randint(0, n_cls, (batch,), generator=g)

@@ -33,7 +33,8 @@ def _bn1d(x, sd, key, train, new_buffers):
 def lfan_forward(inputs, sd, modalities, modal_dim=32, num_heads=2, train=False,
                  backbone_train=None, masks=None, new_buffers=None):
     """inputs: dict with keys in ``modalities`` order:
-    video [B,L,3,H,W]; vggish [B,1,L,128]; bert [B,1,L,768]  ->  [B,L,n_cls].
+    video [B,L,3,H,W]; vggish [B,1,L,128]; bert [B,1,L,768]; logmel [B,64,L,96] (model.py:500-508: one 96 x 64
+    log-mel example per clip frame, run through VGGish inside forward)  ->  [B,L,n_cls].
 
     ``masks`` (train only, optional) = {"head": [B*L,512,h,w], "tcn": {m: [(m1,m2)..]},
     "fusion": [B,L,modal_dim*M]} pre-scaled dropout masks; missing -> identity.
@@ -51,6 +52,11 @@ def lfan_forward(inputs, sd, modalities, modal_dim=32, num_heads=2, train=False,
             x = ir50_forward(x.reshape(-1, *x.shape[2:]), sd, "spatial.visual.backbone.",
                              train=backbone_train, head_dropout_mask=masks.get("head"),
                              new_buffers=new_buffers)
+            x = x.view(bsz, length, -1)
+        elif m == "logmel":
+            from .vggish import vggish_forward
+            bsz, height, length, width = x.shape
+            x = vggish_forward(x.permute(0, 2, 3, 1).reshape(-1, width, height), sd, "spatial.audio.backbone.")
             x = x.view(bsz, length, -1)
         else:
             x = x.squeeze(1)

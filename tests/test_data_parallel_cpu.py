@@ -112,3 +112,47 @@ def test_overlapped_bucket_exchange_equals_the_single_all_reduce():
                 assert torch.allclose(a, b, rtol=0, atol=1e-7) and a.abs().sum() > 0
         for a, b in zip(out[0][True], out[1][True]):
             assert torch.equal(a, b)
+
+
+def _worker_rank_dependent_graph(rank, world, port, out):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from feature_vs_text_compound_emotion_amd.data_parallel import ClipDataParallel, init_process_group_from_env
+    import torch.distributed as dist
+    init_process_group_from_env(backend="gloo")
+    res = {}
+    for overlap in (False, True):
+        torch.manual_seed(9)
+        model = torch.nn.Sequential(torch.nn.Linear(40, 64), torch.nn.Linear(64, 64), torch.nn.Linear(64, 48),
+                                    torch.nn.Linear(48, 16), torch.nn.Linear(16, 3))
+        ddp = ClipDataParallel(model, overlap=overlap, bucket_mb=8 / 1024)
+        if overlap:
+            assert len(ddp.buckets) >= 4
+        g = torch.Generator().manual_seed(3 + rank)
+        ddp.zero_grad()
+        x = torch.randn(6, 40, generator=g)
+        h = model[1](model[0](x))
+        if rank == 1:                     # a data-dependent branch: rank 1 skips a layer in the MIDDLE of the model this step
+            h = h[:, :48]
+        else:
+            h = model[2](h)
+        model[4](model[3](h)).square().mean().backward()
+        ddp.all_reduce_gradients()
+        res[overlap] = ddp.flat.clone()
+    out[rank] = res
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_exchange_keeps_one_collective_order_when_a_rank_skips_a_layer():
+    """ADVICE (round 2): a slice whose parameters get no gradient on ONE rank must not change the order in which that rank
+    issues its collectives (differently sized all-reduces would pair up across ranks: a gloo size error, a silent
+    mis-reduction or a hang on RCCL).  Slices go out strictly last-to-first; the skipped one and everything below it wait for
+    all_reduce_gradients() on the rank that skipped.  Result == the single all-reduce, identical on both ranks."""
+    world, port = 2, _free_port()
+    with mp.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_rank_dependent_graph, args=(world, port, out), nprocs=world, join=True)
+        for rank in (0, 1):
+            assert torch.allclose(out[rank][False], out[rank][True], rtol=0, atol=1e-7) and out[rank][True].abs().sum() > 0
+        assert torch.equal(out[0][True], out[1][True])

@@ -133,3 +133,16 @@ def test_can_jmt_mt_heads_match_reference():
         with torch.no_grad():
             out = can_forward(x, sd, mods) if name == "CAN" else jmt_forward(x, sd, mods, model_name=name)
         assert np.abs(out.numpy() - g[f"{name}_eval_logits"]).max() < TOL
+
+
+def test_lfan_with_the_on_model_vggish_matches_reference():
+    """'logmel' modality: VGGish inside forward (models/model.py:458-461,500-508); tools/gen_golden_logmel.py."""
+    g = golden("lfan_logmel.npz")
+    b, l, ncls, wseed, dseed = [int(v) for v in g["meta"]]
+    mods = ["logmel", "vggish"]
+    spec, alias = synth.lfan_spec(mods, n_cls=ncls)
+    sd = synth.make_state_dict(spec, alias, seed=wseed)
+    x, _ = synth.make_clip_batch(mods, b, l, seed=dseed)
+    with torch.no_grad():
+        out = lfan_forward(x, sd, mods)
+    assert np.abs(out.numpy() - g["logits"]).max() < TOL

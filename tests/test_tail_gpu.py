@@ -259,6 +259,34 @@ def test_lfan_modality_subsets_and_order():
         assert np.abs(logits.cpu().numpy() - g["logits_" + "_".join(mods)]).max() < 1e-4
 
 
+def test_lfan_logmel_modality_key_order_and_dict_write_back():
+    """Boundary details of LFAN.forward (models/model.py:487-526) against a fixture from the reference
+    (tools/gen_golden_logmel.py): the 'logmel' modality runs VGGish inside forward; the caller's dict may come in any key
+    order (the fusion walks the model's modality list); afterwards it holds the per-modality features [B, L, C_m]; a key the
+    model was not built for is a KeyError."""
+    from feature_vs_text_compound_emotion_amd import synth
+    g = golden("lfan_logmel.npz")
+    b, l, ncls, wseed, dseed = [int(v) for v in g["meta"]]
+    mods = ["logmel", "vggish"]
+    spec, alias = synth.lfan_spec(mods, n_cls=ncls)
+    sd = synth.make_state_dict(spec, alias, seed=wseed)
+    x, _ = synth.make_clip_batch(mods, b, l, seed=dseed)
+    model = _build_lfan(mods, sd, l, n_cls=ncls).eval()
+    with torch.no_grad():
+        caller = {k: v.cuda() for k, v in x.items()}
+        logits = model(caller)
+        swapped = model({k: x[k].cuda() for k in reversed(mods)})
+    assert np.abs(logits.cpu().numpy() - g["logits"]).max() < 1e-4
+    assert torch.equal(logits, swapped)
+    for m in mods:      # what the reference leaves in the dict it was handed
+        assert tuple(caller[m].shape) == g["left_" + m].shape
+        assert np.abs(caller[m].cpu().numpy() - g["left_" + m]).max() < 1e-4, m
+    with pytest.raises(KeyError):
+        model({"logmel": x["logmel"].cuda(), "vggish": x["vggish"].cuda(), "bert": torch.zeros(b, 1, l, 768).cuda()})
+    with pytest.raises(KeyError):
+        model({"logmel": x["logmel"].cuda()})
+
+
 @pytest.mark.parametrize("tag", ["refmode", "evalbackbone"])
 def test_lfan_two_training_steps_match_reference_fixture(tag):
     """trainer.py:365-391 on the HIP path: zero_grad, forward, CE, backward, Nesterov SGD (lr 1e-3).
