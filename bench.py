@@ -272,7 +272,7 @@ class Workload:
 
     def inputs(self):
         if self.fx is None:
-            return self.x
+            return dict(self.x)      # the model overwrites the dict it is handed, like the reference (model.py:487-515)
         length = self.cfg["length"]
         out = {}
         for m in self.cfg["modalities"]:  # raw audio + token ids -> per-frame features on the GPU (frozen encoders)

@@ -120,4 +120,27 @@ def test_trainer_inference_device_and_host_aggregation_agree_on_the_hip_model():
     _same(perf_d, perf_h)
     for k in pv_h:
         assert np.abs(pv_d[k]["logits"] - pv_h[k]["logits"]).max() < 1e-5
-    assert tr.inference(loader)[1] == {}      # default: nothing copied per video
+    # default: the reference's return contract (per-video logits, trainer.py:500-523); keep_logits=False skips the copies
+    assert set(tr.inference(loader)[1]) == set(pv_h)
+    assert tr.inference(loader, keep_logits=False)[1] == {}
+    # ADVICE (round 2): windows are forwarded in groups bounded by a frame budget (default: the training footprint,
+    # train_batch_size x window_length) instead of all at once; 37 frames / window 8 / hop 5 = 7 windows in groups of 2
+    long = {"vggish": torch.randn(1, 1, 37, 128, generator=g).cuda(), "bert": torch.randn(1, 1, 37, 768, generator=g).cuda()}
+    tr.eval_frame_budget = 16
+    calls = []
+    hook = model.register_forward_pre_hook(lambda mod, args: calls.append(next(iter(args[0].values())).shape[0]))
+    with torch.no_grad():
+        dev = tr.inference_forward_windows(dict(long))
+        assert calls == [2, 2, 2, 1], calls
+        host = tr.inference_forward_windows(dict(long), aggregate="host")
+    hook.remove()
+    assert tuple(dev.shape) == (1, 37, 7) and (dev - host).abs().max().item() < 1e-5
+    # a batch of several videos takes the host path (the stitch kernel handles one video per call)
+    two = {k: torch.cat([v, v.flip(2)], dim=0) for k, v in long.items()}
+    with torch.no_grad():
+        out2 = tr.inference_forward_windows(dict(two))
+    assert tuple(out2.shape) == (2, 37, 7) and (out2[0] - host[0]).abs().max().item() < 1e-5
+    # pointers are validated before they reach a kernel
+    from feature_vs_text_compound_emotion_amd.eval_device import stitch_windows
+    with pytest.raises(ValueError):
+        stitch_windows(torch.zeros(2, 8, 7), [0, 5], 13)

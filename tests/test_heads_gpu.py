@@ -36,7 +36,7 @@ def test_head_eval_and_training_step_match_reference_fixture(name):
     xd = {k: v.cuda() for k, v in x.items()}
     model = _build(name, sd).eval()
     with torch.no_grad():
-        logits = model(xd)
+        logits = model(dict(xd))      # the model overwrites the caller's dict like the reference (model.py:651-662)
     assert np.abs(logits.cpu().numpy() - g[f"{name}_eval_logits"]).max() < 1e-4
     # one optimisation step exactly as the reference runs it (model.train()), dropout off
     model = _build(name, sd).train()
@@ -45,7 +45,7 @@ def test_head_eval_and_training_step_match_reference_fixture(name):
     for mod in model.modules():
         if isinstance(mod, torch.nn.Dropout):
             mod.p = 0.0
-    out = model(xd)
+    out = model(dict(xd))
     loss = cross_entropy_loss(out, labels.cuda())
     loss.backward()
     assert abs(loss.item() - float(g[f"{name}_train_loss"])) < 1e-4

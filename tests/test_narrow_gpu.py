@@ -10,13 +10,16 @@ Bars (round 3: every bar states its origin and can fail).
   also narrows the tail, the HIP modes only the encoder).  IR-50 EMBEDDINGS: the encoder is the same arithmetic class as
   autocast (16-bit tensors, fp32 accumulate; on the CPU the two land within 8 % of each other), so the bar is 1.25 x the
   yardstick and 1.5 x the storage-only emulation -- two rounding realisations of one format.
-* Absolute: SURVEY section 7's cfg5 bar -- |logit error| <= 2e-2 and argmax agreement -- in eval mode for both storage types,
-  4e-3 for fp16 in BOTH modes (no allowance).  bf16 in ``model.train()``: 3.5e-2.  Not 2e-2, and the reason is demonstrated
-  on the CPU by tests/test_conditioning_cpu.py: train mode normalises the video features by their batch statistics, so the
-  embedding error enters the logits at full weight (eval mode hides it behind synthetic running statistics ~1000x the
-  actual variance); bf16 STORAGE ALONE -- every tensor rounded once, everything else fp32, no kernel involved -- lands at
-  2.2e-2 on this batch and the reference's autocast arithmetic at 5.2e-2.  3.5e-2 = that floor x 1.6 for the spread of a
-  maximum over 1024 logits between two rounding realisations.
+* Absolute, eval mode: SURVEY section 7's cfg5 bar -- |logit error| <= 2e-2 and argmax agreement -- for both storage types,
+  4e-3 for fp16.
+* ``model.train()`` (the mode the reference trains in and bench.py times): the bar is 1.6 x the FLOOR OF THE STORAGE FORMAT,
+  computed inside the test: the fp32 oracle with every tensor rounded once to the storage type and everything else fp32
+  (oracle/narrow.py -- no kernel involved) gives 2.2e-2 (bf16) / 3.1e-3 (fp16) on this batch; 1.6 covers the spread of a
+  maximum over 1024 logits between two rounding realisations (the same kernels measured 2.8e-3 and 4.0e-3 for fp16 in two
+  rounds).  SURVEY's 2e-2 / this file's former 4e-3 came from EVAL-mode measurements, where the synthetic running
+  statistics of bn.video (variance ~1) are ~1000x the actual variance of the video temporal net's output and hide the
+  embedding error; train mode normalises by the batch statistics and the error enters at full weight -- for the reference's
+  own autocast arithmetic too (4.8e-2 / 6.4e-3).  tests/test_conditioning_cpu.py demonstrates all of this on the CPU.
 * Embeddings (unit-norm 512-d rows, elements ~0.044): relative L2 and cosine -- an element-wise bound of a few 1e-2 on
   0.044-sized numbers cannot fail (round-2 verdict) and is gone.
 """
@@ -31,7 +34,7 @@ DT = {"bf16": torch.bfloat16, "fp16": torch.float16}
 EMB_REL = {"bf16": 2.5e-2, "fp16": 3.2e-3}    # relative L2 of the [N,512] embedding matrix (storage-only emulation: 1.7e-2 / 2.1e-3 in train mode)
 EMB_COS = {"bf16": 0.9992, "fp16": 0.99999}   # worst row cosine: 1 - rel^2/2 at twice the relative bar
 LOGIT_BAR = {"bf16": 2e-2, "fp16": 4e-3}
-TRAIN_LOGIT_BAR = {"bf16": 3.5e-2, "fp16": 4e-3}
+FLOOR_FACTOR = 1.6
 YARDSTICK = 0.8          # logits
 YARDSTICK_EMB = 1.25     # embeddings
 
@@ -125,7 +128,8 @@ def test_cfg5_trimodal_64_frame_clips_8_classes(precision):
     from feature_vs_text_compound_emotion_amd import synth
     from feature_vs_text_compound_emotion_amd.lfan import cross_entropy_loss
     from oracle.lfan import cross_entropy_mean, lfan_forward
-    from oracle.narrow import autocast_lfan_forward
+    import oracle.lfan as oracle_lfan
+    from oracle.narrow import autocast_lfan_forward, ir50_forward_narrow_storage
     b, length, hw, n_cls = 2, 64, 40, 8
     sd = synth.lfan_state_dict(MODS, n_cls=n_cls, head_hw=hw // 8, seed=0)
     x, labels = synth.make_clip_batch(MODS, b, length, hw=hw, seed=4321, n_cls=n_cls)
@@ -161,13 +165,21 @@ def test_cfg5_trimodal_64_frame_clips_8_classes(precision):
     with torch.no_grad():
         oref = lfan_forward(x, sd, MODS, train=True, backbone_train=True)
         tyard = (autocast_lfan_forward(x, sd, MODS, DT[precision], train=True, backbone_train=True) - oref).abs().max().item()
+        # the storage format's floor: the oracle's tail on the storage-only emulation of the embedding
+        emb = ir50_forward_narrow_storage(x["video"].reshape(-1, 3, hw, hw), sd, "spatial.visual.backbone.", DT[precision])
+        orig = oracle_lfan.ir50_forward
+        oracle_lfan.ir50_forward = lambda *a, **k: emb
+        try:
+            floor = (lfan_forward(x, sd, MODS, train=True, backbone_train=True) - oref).abs().max().item()
+        finally:
+            oracle_lfan.ir50_forward = orig
     oloss = cross_entropy_mean(oref, labels)
     diff = out.detach().cpu() - oref
     terr, trms = diff.abs().max().item(), diff.pow(2).mean().sqrt().item()
     tagree = (out.detach().cpu().argmax(-1) == oref.argmax(-1)).float().mean().item()
-    print(f"[narrow {precision}] cfg5 train forward: max |logit err| {terr:.2e} (rms {trms:.2e}; reference autocast arithmetic "
-          f"{tyard:.2e}), argmax agreement {tagree:.4f}, loss {loss.item():.6f} vs oracle {oloss.item():.6f}")
-    assert terr < TRAIN_LOGIT_BAR[precision]        # module docstring: origin of the bf16 number
+    print(f"[narrow {precision}] cfg5 train forward: max |logit err| {terr:.2e} (rms {trms:.2e}; storage-only emulation {floor:.2e}, "
+          f"reference autocast arithmetic {tyard:.2e}), argmax agreement {tagree:.4f}, loss {loss.item():.6f} vs oracle {oloss.item():.6f}")
+    assert terr < FLOOR_FACTOR * floor              # module docstring
     assert terr < YARDSTICK * tyard
     assert tagree > 0.95
     assert abs(loss.item() - oloss.item()) < LOGIT_BAR[precision] / 4
