@@ -223,6 +223,7 @@ class Workload:
                 for part in (bb.input_layer, bb.body, bb.output_layer):
                     for p in part.parameters():
                         p.requires_grad = True
+            self.model.spatial["visual"].backbone.activation_memory = cfg["act_mem"]
         # released encoder units (28-43 M parameters): exchange 25 MB slices of the bucket under the backward of the units below
         self.ddp = ClipDataParallel(self.model, world_size=world, overlap=cfg["release"] > 0)
         # the reference's torch.optim.SGD(momentum .9, nesterov, wd 1e-4, lr 1e-3 -- F8) as one fused launch over flat buffers
@@ -248,10 +249,14 @@ class Workload:
         cfg, dev = self.cfg, self.dev
         ab = AudioBackbone()
         ab.backbone.load_state_dict(synth.make_state_dict(synth.vggish_spec(""), seed=21), strict=True)
+        if cfg["precision"] in NARROW:   # the narrow modes cover the whole tri-modal step: VGGish and BERT follow IR-50
+            ab.backbone.precision = cfg["precision"]
         te = None
         if "bert" in cfg["modalities"]:
             te = BertEncoderHIP()
             te.load_state_dict(synth.make_state_dict(synth.bert_spec(""), seed=31), strict=True)
+            if cfg["precision"] in NARROW:
+                te.precision = cfg["precision"]
         self.fx = MultimodalFeatureExtractor(ab, te if te is not None else torch.nn.Identity(), fps=32).to(dev).eval()
         secs = cfg["length"] / 32.0
         pcm = torch.stack([synth.make_audio_int16(secs, 16000, seed=5000 + rank * 1000 + i) for i in range(cfg["batch"])])
@@ -432,6 +437,7 @@ class Workload:
                        "model": cfg["model"], "modalities": mods, "encoders_on_gpu": cfg["encoders"] == "on",
                        "clips_per_gpu": cfg["batch"], "global_batch": cfg["batch"] * self.world, "frames_per_clip": cfg["length"],
                        "frame_hw": cfg["hw"], "n_classes": cfg["n_cls"], "released_encoder_groups": cfg["release"],
+                       "released_units_activation_memory": cfg["act_mem"] if cfg["release"] else None,
                        "trainable_parameters": int(sum(p.numel() for p in self.ddp.params)), "conv_precision": cfg["precision"],
                        "parallelism": f"dp{self.world} over clips, flat-bucket RCCL all-reduce", "loss": float(loss.item())},
             "roofline": roofline}
@@ -480,6 +486,10 @@ def main():
                     help="gradual-release groups of the reference's ResnetParamControl to un-freeze before timing "
                          "(0 = as the reference trains: encoder frozen; 1 = output layer; 2 = + stage 4; 3 = + half of stage 3; "
                          "4 = extension: the whole IR-50 trains, forward + backward through every unit and the stem)")
+    ap.add_argument("--act-mem", choices=["auto", "raw", "recompute"], default="auto",
+                    help="released encoder units: raw = keep the raw conv results for the backward (410 MB per 224x224 frame); "
+                         "recompute = keep unit inputs as one fp16 plane (62 MB per frame) and re-run the unit's convs in the "
+                         "backward; auto = recompute when the raw tensors of the batch would not fit (> 384 frames of 224x224)")
     ap.add_argument("--encoders", choices=["on", "off"], default="on",
                     help="on: VGGish (log-mel from PCM) and BERT (64 tokens) run on the GPU inside the step; "
                          "off: pre-computed per-frame features, as the reference trainer feeds them")
@@ -502,6 +512,8 @@ def main():
     mods = a.modalities.split(",") if a.modalities else (ALL_MODS if a.model == "LFAN" else ["video", "vggish"])
     cfg = {"model": a.model, "modalities": mods, "hw": a.hw, "batch": a.batch, "length": a.length, "n_cls": a.n_cls,
            "precision": a.precision, "release": a.release, "encoders": a.encoders}
+    raw_bytes = 410e6 * (a.hw / 224.0) ** 2 * a.batch * a.length    # raw tensors of all 24 units + the stem, fp32
+    cfg["act_mem"] = a.act_mem if a.act_mem != "auto" else ("recompute" if a.release == 4 and raw_bytes > 160e9 else "raw")
     wl = Workload(cfg, rank, world, dev)
     res = wl.measure(a.steps, a.warmup)
     wl.close()

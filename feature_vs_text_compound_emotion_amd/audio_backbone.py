@@ -61,7 +61,9 @@ class VGGish(nn.Module):
                                         nn.Linear(4096, 128))
         self._packed, self._key = None, None
         self._mel = None
-        # "bf16x3": convs 2-6 and the three FCs on the split-bf16 kernels (<= 2^-15 relative per product); "fp32": exact fp32
+        # "bf16x3": convs 2-6 and the three FCs on the split-bf16 kernels (<= 2^-15 relative per product); "fp32": exact fp32;
+        # "bf16" / "fp16": narrow storage (one 16-bit plane per tensor, one MFMA per product, fp32 accumulate) -- what the
+        # reference's autocast computes (trainer.py:367) and BASELINE cfg5's "bf16" asks of the whole tri-modal step
         self.precision = "bf16x3"
 
     def _pack(self):
@@ -74,6 +76,14 @@ class VGGish(nn.Module):
                             "fc_b3": [ops.split_bf16(self.embeddings[i].weight.detach().contiguous()) for i in (0, 2, 4)]}
             self._key = key
         return self._packed
+
+    def _pack_n16(self, dtype):
+        packed = self._pack()
+        if packed.get("n16_dtype") != dtype:
+            packed["convs_n16"] = [None] + [ops.to_n16(w, dtype) for w in packed["convs"][1:]]
+            packed["fc_n16"] = [ops.to_n16(self.embeddings[i].weight.detach().contiguous(), dtype) for i in (0, 2, 4)]
+            packed["n16_dtype"] = dtype
+        return packed
 
     def __deepcopy__(self, memo):
         import copy
@@ -94,6 +104,10 @@ class VGGish(nn.Module):
         n = x.shape[0]
         if self.precision == "bf16x3":
             return self._forward_b3(x, packed, n)
+        if self.precision in ("bf16", "fp16"):
+            return self._forward_n16(x, n, torch.bfloat16 if self.precision == "bf16" else torch.float16)
+        if self.precision != "fp32":
+            raise ValueError(f"unknown precision {self.precision!r}")
         packed = packed["convs"]
         y = x.view(n, 1, x.shape[1], x.shape[2])  # NCHW with C = 1
         for j, i in enumerate(CONV_IDX):
@@ -127,6 +141,27 @@ class VGGish(nn.Module):
         e = ops.conv2d_b3(e, packed["fc_b3"][1], 1, 1, bias=fc[2].bias.detach(), act1=ops.ACT_RELU, split_k=split)["split"]
         return ops.conv2d_b3(e, packed["fc_b3"][2], 1, 1, bias=fc[4].bias.detach(), split_k=split, out_f32=True,
                              out_split=False)["y"].view(n, -1)
+
+    def _forward_n16(self, x, n, dtype):
+        """Narrow storage: layer 1 (Cin = 1) on the fp32 small-Cin kernel, convs 2-6 and the FCs on the narrow kernels.  A
+        conv that feeds a max-pool writes fp32 (pooling wants the un-rounded value) and the pooled map is rounded once."""
+        packed = self._pack_n16(dtype)
+        feats, fc = self.features, self.embeddings
+        y = ops.conv2d(x.view(n, 1, x.shape[1], x.shape[2]), packed["convs"][0], 3, 3, pad=(1, 1),
+                       bias=feats[0].bias.detach(), act1=ops.ACT_RELU, x_nchw=True)
+        cur = ops.to_n16(ops.maxpool2x2_nhwc(y), dtype)
+        for j, i in list(enumerate(CONV_IDX))[1:]:
+            pooled = i in POOL_AFTER
+            r = ops.conv2d_n16(cur, packed["convs_n16"][j], 3, 3, pad=(1, 1), bias=feats[i].bias.detach(), act1=ops.ACT_RELU,
+                               out_f32=pooled, out_n16=not pooled)
+            cur = ops.to_n16(ops.maxpool2x2_nhwc(r["y"]), dtype) if pooled else r["n16"]
+        k = cur.numel() // n
+        e = cur.view(n, 1, 1, k)
+        split = max(1, min(8, 512 // max(1, (n + 127) // 128 * 32)))
+        e = ops.conv2d_n16(e, packed["fc_n16"][0], 1, 1, bias=fc[0].bias.detach(), act1=ops.ACT_RELU, split_k=split)["n16"]
+        e = ops.conv2d_n16(e, packed["fc_n16"][1], 1, 1, bias=fc[2].bias.detach(), act1=ops.ACT_RELU, split_k=split)["n16"]
+        return ops.conv2d_n16(e, packed["fc_n16"][2], 1, 1, bias=fc[4].bias.detach(), split_k=split, out_f32=True,
+                              out_n16=False)["y"].view(n, -1)
 
     # ---------------------------------------------------------------- front end
     def wav_int16_to_examples(self, pcm_int16, sample_rate, window_sec=0.96, hop_sec=0.96):

@@ -65,6 +65,11 @@ class BertEncoderHIP(nn.Module):
         for p in self.parameters():
             p.requires_grad = False
         self._packed, self._key = None, None
+        # "fp32": exact fp32 MFMA GEMMs; "bf16" / "fp16": the GEMM operands (activations and weights) as one 16-bit plane, one
+        # MFMA per product, fp32 accumulate -- what autocast does to nn.Linear (the reference's --amp recipe); attention,
+        # LayerNorm, GELU, residuals and the hidden-state sum stay fp32
+        self.precision = "fp32"
+        self._packed_n16 = None
 
     def _pack(self):
         key = tuple((p.data_ptr(), p._version) for p in self.parameters())
@@ -79,9 +84,28 @@ class BertEncoderHIP(nn.Module):
             self._packed, self._key = packed, key
         return self._packed
 
+    def _pack_n16(self, dtype):
+        packed = self._pack()
+        if self._packed_n16 is None or self._packed_n16[0] != (dtype, self._key):
+            layers = []
+            for (wqkv, _), L in zip(packed, self.encoder.layer):
+                layers.append(tuple(ops.to_n16(w.detach().contiguous(), dtype) for w in
+                                    (wqkv, L.attention.output.dense.weight, L.intermediate.dense.weight, L.output.dense.weight)))
+            self._packed_n16 = ((dtype, self._key), layers)
+        return self._packed_n16[1]
+
+    @staticmethod
+    def _linear_n16(x, w16, bias, act=ops.ACT_NONE, residual=None):
+        """y = act(x @ w^T + bias) + residual with narrow operands: x [rows, K] fp32 is rounded once, the result is fp32."""
+        rows, k = x.shape
+        r = None if residual is None else residual.view(rows, 1, 1, -1)
+        return ops.conv2d_n16(ops.to_n16(x, w16.dtype).view(rows, 1, 1, k), w16, 1, 1, bias=bias, act1=act, residual=r,
+                              out_f32=True, out_n16=False)["y"].view(rows, -1)
+
     def __deepcopy__(self, memo):
         import copy
         packed, self._packed = self._packed, None
+        self._packed_n16 = None
         try:
             new = self.__class__.__new__(self.__class__)
             memo[id(self)] = new
@@ -106,8 +130,14 @@ class BertEncoderHIP(nn.Module):
         n_layers = len(self.encoder.layer)
         if last_n_sum > n_layers:
             total = x.clone()
+        if self.precision not in ("fp32", "bf16", "fp16"):
+            raise ValueError(f"unknown precision {self.precision!r}")
+        n16 = None if self.precision == "fp32" else self._pack_n16(torch.bfloat16 if self.precision == "bf16" else torch.float16)
         for i, L in enumerate(self.encoder.layer):
             wqkv, bqkv = packed[i]
+            if n16 is not None:
+                x, total = self._layer_n16(x, total, i, L, n16[i], bqkv, b, s, mask, n_layers, last_n_sum)
+                continue
             qkv = ops.linear(x, wqkv, bias=bqkv)  # [tokens, 3*hidden]
             ctx = torch.empty((b * s, hd), device=dev, dtype=torch.float32)
             st = (s * 3 * hd, 3 * hd, hdim)
@@ -122,6 +152,24 @@ class BertEncoderHIP(nn.Module):
             if i >= n_layers - last_n_sum:
                 total = x.clone() if total is None else ops.add_inplace(total, x)
         return total.view(b, s, hd)
+
+    def _layer_n16(self, x, total, i, L, w16, bqkv, b, s, mask, n_layers, last_n_sum):
+        hd, H, hdim = self.hidden, self.heads, self.hidden // self.heads
+        wqkv, wo, wi, wf = w16
+        qkv = self._linear_n16(x, wqkv, bqkv)
+        ctx = torch.empty((b * s, hd), device=x.device, dtype=torch.float32)
+        st = (s * 3 * hd, 3 * hd, hdim)
+        ops.attention(qkv, qkv[:, hd:], qkv[:, 2 * hd:], ctx, b, H, s, s, hdim, st, st, st, (s * hd, hd, hdim),
+                      1.0 / hdim ** 0.5, key_mask=mask)
+        ao = L.attention.output
+        y = self._linear_n16(ctx, wo, ao.dense.bias, residual=x)
+        x1, _, _ = ops.layernorm_fwd(y, ao.LayerNorm.weight, ao.LayerNorm.bias, eps=LN_EPS, save=False)
+        inter = self._linear_n16(x1, wi, L.intermediate.dense.bias, act=ops.ACT_GELU)
+        y2 = self._linear_n16(inter, wf, L.output.dense.bias, residual=x1)
+        x, _, _ = ops.layernorm_fwd(y2, L.output.LayerNorm.weight, L.output.LayerNorm.bias, eps=LN_EPS, save=False)
+        if i >= n_layers - last_n_sum:
+            total = x.clone() if total is None else ops.add_inplace(total, x)
+        return x, total
 
     @staticmethod
     def exclude_padding(token_vecs_sum, attention_mask):

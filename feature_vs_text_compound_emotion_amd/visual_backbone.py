@@ -117,10 +117,17 @@ class _ReleasedUnit(torch.autograd.Function):
     kept anyway), the two raw conv results ``z1`` / ``z2`` (and the raw shortcut conv ``zs``), 12-16 bytes per unit element
     -- and the two conv INPUTS are recomputed there: ``BN1(x)`` from the saved batch statistics (one fused affine + split
     pass) and ``PReLU(z1)``.  Round 2 also kept both conv inputs as split tensors (+8 bytes per element: 218 -> 131 MB per
-    224x224 frame over the whole encoder), which is what stopped B = 32 x 32 frames from fitting the 288 GB."""
+    224x224 frame over the whole encoder).
+
+    ``memory == "recompute"`` (``IR50.activation_memory``, what BASELINE configs[1] at B = 32 x 32 frames of 224x224 needs:
+    stage 1 of this IR-50 runs at the full 224x224, so even the raw tensors are 410 MB per frame = 420 GB per step): a unit
+    keeps only its INPUT, as one fp16 plane (2 bytes per element: 62 MB per frame, 64 GB per step), and the backward runs the
+    unit's two convs again from it with the saved batch statistics -- one extra forward of the encoder per step (+1/3 of
+    the conv work) for 6.6x less activation memory.  The rounding of the saved input to fp16 (2^-11 relative) enters the
+    gradients at that level (tests/test_head_release_gpu.py states the bar); forward results are unchanged."""
 
     @staticmethod
-    def forward(ctx, x, u, prec, g1, b1, w1, a1, w2, g2, b2, ws, gs, bs):
+    def forward(ctx, x, u, prec, memory, g1, b1, w1, a1, w2, g2, b2, ws, gs, bs):
         n, h, w, cin = x.shape
         bn1, bn2, s = u.res_layer[0], u.res_layer[4], u.stride
         xb, sm1, si1 = ops.bn_rows_fwd(x.view(-1, cin), g1.detach(), b1.detach(), bn1.running_mean, bn1.running_var, True,
@@ -149,11 +156,16 @@ class _ReleasedUnit(torch.autograd.Function):
             ops.add_inplace(out, sc.view(n, ho, wo, depth))
         else:
             ops.add_inplace(out, x[:, ::s, ::s].contiguous() if s > 1 else x)  # MaxPool2d(1, s) == subsample
-        ctx.save_for_backward(x, z1, z2, sm1, si1, sm2, si2, zs, sms, sis, g1.detach(), b1.detach(), w1.detach(),
+        if memory == "recompute":   # keep ONE 16-bit plane of the unit input; z1 / z2 / zs are rebuilt from it in the backward
+            xk, z1, z2, zs = x.to(torch.float16), None, None, None
+        else:
+            xk = x
+        ctx.save_for_backward(xk, z1, z2, sm1, si1, sm2, si2, zs, sms, sis, g1.detach(), b1.detach(), w1.detach(),
                               a1.detach(), w2.detach(), g2.detach(), ws.detach() if ws is not None else None,
                               gs.detach() if gs is not None else None)
         ctx.stride = s
         ctx.prec = prec
+        ctx.out_shape = tuple(out.shape)
         return out
 
     @staticmethod
@@ -167,28 +179,37 @@ class _ReleasedUnit(torch.autograd.Function):
         # 2^-15 per product) -- scaled or not, nothing underflows.
         dprec = "bf16x3" if prec == "fp16" else prec
         n, h, w, cin = x.shape
-        _, ho, wo, depth = z2.shape
+        _, ho, wo, depth = ctx.out_shape
         dout = dout.contiguous()
-        dz2, dg2, db2 = ops.bn_rows_bwd(dout.view(-1, depth), z2.view(-1, depth), sm2, si2, g2)
-        dz2 = dz2.view(n, ho, wo, depth)
         b3 = prec != "fp32"   # the weight gradients follow the convs onto the bf16x3 matrix-core kernel
         split = prec == "bf16x3"   # operands split once per tensor, shared by the weight and the data gradient
+        sc1, sh1 = _bn_affine_from_saved(sm1, si1, g1, b1)
+        recompute = z2 is None
+        if recompute:              # "recompute" memory plan: the unit's forward again, with the SAVED batch statistics
+            x = x.float()
+        xb = ops.split_bf16(x, sc1, sh1) if split else torch.addcmul(sh1, x, sc1)   # BN1(x) (and split) in one pass
+        if recompute:
+            z1 = _conv_prec(xb, ops.pack_conv_weight(w1.contiguous()), 3, 3, 1, (1, 1), prec)
         t1 = ops.prelu_fwd(z1, a1.contiguous())                 # recomputed conv input (see the class docstring)
         if split:
             t1 = ops.split_bf16(t1)
+        if recompute:
+            z2 = _conv_prec(t1, ops.pack_conv_weight(w2.contiguous()), 3, 3, s, (1, 1), prec)
+            if ws is not None:
+                zs = _conv_prec(x, ops.pack_conv_weight(ws.contiguous()), 1, 1, s, (0, 0), prec)
+        dz2, dg2, db2 = ops.bn_rows_bwd(dout.view(-1, depth), z2.view(-1, depth), sm2, si2, g2)
+        del z2
+        dz2 = dz2.view(n, ho, wo, depth)
+        if split:
             dz2 = ops.split_bf16(dz2)
         dw2 = ops.conv2d_wgrad(dz2, t1, 3, 3, stride=s, pad=(1, 1), b3=b3)
         del t1
         dt1 = _conv_dgrad(dz2, w2, s, 1, (h, w), dprec)
         del dz2
         dz1, da1 = ops.prelu_bwd(dt1, z1, a1.contiguous())
-        del dt1
-        sc1, sh1 = _bn_affine_from_saved(sm1, si1, g1, b1)
+        del dt1, z1
         if split:
             dz1 = ops.split_bf16(dz1)
-            xb = ops.split_bf16(x, sc1, sh1)                    # BN1(x) recomputed and split in one pass
-        else:
-            xb = torch.addcmul(sh1, x, sc1)
         dw1 = ops.conv2d_wgrad(dz1, xb, 3, 3, stride=1, pad=(1, 1), b3=b3)
         del xb
         need_dx = ctx.needs_input_grad[0]
@@ -215,7 +236,7 @@ class _ReleasedUnit(torch.autograd.Function):
                 dx[:, ::s, ::s] += dout
             else:
                 ops.add_inplace(dx, dout)
-        return (dx if need_dx else None), None, None, dg1, db1, dw1, da1, dw2, dg2, db2, dws, dgs, dbs
+        return (dx if need_dx else None), None, None, None, dg1, db1, dw1, da1, dw2, dg2, db2, dws, dgs, dbs
 
 
 class _ReleasedStem(torch.autograd.Function):
@@ -330,6 +351,9 @@ class IR50(nn.Module):
         self._packed_train_n16_key = None
         self.dropout_seed = 0
         self._dropout_calls = 0
+        # released units: "raw" keeps the raw conv results for the backward (fp32), "recompute" keeps the unit inputs as one
+        # fp16 plane and re-runs the unit's convs in the backward (_ReleasedUnit)
+        self.activation_memory = "raw"
 
     def __deepcopy__(self, memo):
         """trainer.py:656,705 deep-copies the model: copy parameters/buffers, not the packed caches."""
@@ -800,11 +824,12 @@ class IR50(nn.Module):
         il = self.input_layer
         return _ReleasedStem.apply(x, il[1], il[0].weight, il[1].weight, il[1].bias, il[2].weight)
 
-    @staticmethod
-    def _released_unit(u, y, prec="fp32"):
+    def _released_unit(self, u, y, prec="fp32"):
+        if self.activation_memory not in ("raw", "recompute"):
+            raise ValueError(f"unknown activation_memory {self.activation_memory!r}")
         pr = u.res_layer
         sc = u.shortcut_layer if u.cin != u.depth else None
-        return _ReleasedUnit.apply(y, u, prec, pr[0].weight, pr[0].bias, pr[1].weight, pr[2].weight, pr[3].weight, pr[4].weight,
+        return _ReleasedUnit.apply(y, u, prec, self.activation_memory, pr[0].weight, pr[0].bias, pr[1].weight, pr[2].weight, pr[3].weight, pr[4].weight,
                                    pr[4].bias, sc[0].weight if sc is not None else None,
                                    sc[1].weight if sc is not None else None, sc[1].bias if sc is not None else None)
 

@@ -198,3 +198,48 @@ def test_attention_fwd_bwd_on_fused_qkv_buffer_with_interleaved_batches(nb, toke
     ops.attention_bwd(d, d[:, E:], d[:, 2 * E:], out, go.cuda(), lse, dqkv, dqkv[:, E:], dqkv[:, 2 * E:], nb, 1, tokens,
                       tokens, E, st, st, st, so, so, st, st, st, 1.0 / E ** 0.5)
     assert (dqkv.cpu() - qkv.grad).abs().max().item() < 5e-5
+
+
+@pytest.mark.parametrize("precision", ["bf16", "fp16"])
+def test_narrow_vggish_and_bert_against_the_autocast_yardstick(precision):
+    """BASELINE cfg5 asks for the WHOLE tri-modal step in bf16: under precision = "bf16" / "fp16" VGGish's convs 2-6 + FCs and
+    BERT's GEMMs take narrow operands (one 16-bit plane, one MFMA per product, fp32 accumulate).  Bar: relative L2 against the
+    fp32 oracle no worse than 1.25 x what the reference's own narrow arithmetic -- the oracle under torch.autocast
+    (trainer.py:367) -- gets on the same inputs (like-for-like: two rounding realisations of one format), plus an absolute cap
+    at 2^-7 (bf16) / 2^-10 (fp16) x 4, i.e. a few storage ulps through 9 (VGGish) / 12 x 4 (BERT) narrow layers."""
+    import oracle
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.audio_backbone import AudioBackbone
+    from feature_vs_text_compound_emotion_amd.text_encoder import BertEncoderHIP
+    dt = {"bf16": torch.bfloat16, "fp16": torch.float16}[precision]
+    cap = 4 * {"bf16": 2.0 ** -7, "fp16": 2.0 ** -10}[precision]
+
+    def rel(a, b):
+        return ((a - b).norm() / b.norm()).item()
+    vsd = synth.make_state_dict(synth.vggish_spec(""), seed=21)
+    ab = AudioBackbone()
+    ab.backbone.load_state_dict(vsd, strict=True)
+    ab.backbone.precision = precision
+    ab = ab.cuda().eval()
+    x = torch.randn(37, 96, 64, generator=torch.Generator().manual_seed(5))
+    with torch.no_grad():
+        ref = oracle.vggish_forward(x, vsd)
+        with torch.autocast("cpu", dtype=dt):
+            yard = rel(oracle.vggish_forward(x, vsd).float(), ref)
+        got = rel(ab(x).cpu(), ref)
+    print(f"\n[narrow {precision}] VGGish: relative L2 {got:.2e}, reference autocast arithmetic {yard:.2e}")
+    assert got < 1.25 * yard and got < cap
+    bsd = synth.make_state_dict(synth.bert_spec(""), seed=31)
+    enc = BertEncoderHIP()
+    enc.load_state_dict(bsd, strict=True)
+    enc.precision = precision
+    enc = enc.cuda().eval()
+    ids, mask = synth.make_token_ids(3, 24, seed=77, pad_from=[24, 17, 9])
+    valid = mask.bool()
+    with torch.no_grad():
+        ref = oracle.bert_token_features(ids, mask, bsd)[valid]
+        with torch.autocast("cpu", dtype=dt):
+            yard = rel(oracle.bert_token_features(ids, mask, bsd).float()[valid], ref)
+        got = rel(enc(ids, mask).cpu()[valid], ref)
+    print(f"[narrow {precision}] BERT sum-of-last-4: relative L2 {got:.2e}, reference autocast arithmetic {yard:.2e}")
+    assert got < 1.25 * yard and got < cap
