@@ -486,7 +486,7 @@ def main():
                     help="gradual-release groups of the reference's ResnetParamControl to un-freeze before timing "
                          "(0 = as the reference trains: encoder frozen; 1 = output layer; 2 = + stage 4; 3 = + half of stage 3; "
                          "4 = extension: the whole IR-50 trains, forward + backward through every unit and the stem)")
-    ap.add_argument("--act-mem", choices=["auto", "raw", "recompute"], default="auto",
+    ap.add_argument("--act-mem", choices=["auto", "raw", "recompute", "recompute16"], default="auto",
                     help="released encoder units: raw = keep the raw conv results for the backward (410 MB per 224x224 frame); "
                          "recompute = keep unit inputs as one fp16 plane (62 MB per frame) and re-run the unit's convs in the "
                          "backward; auto = recompute when the raw tensors of the batch would not fit (> 384 frames of 224x224)")

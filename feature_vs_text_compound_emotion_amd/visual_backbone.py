@@ -102,6 +102,23 @@ def _conv_dgrad(dy, w_oihw, stride, pad, in_hw, prec="fp32"):
     return dx
 
 
+def _prelu_bwd_chunked(dy, x, alpha, max_bytes=4 << 30):
+    """``ops.prelu_bwd`` over frame chunks: the kernel writes a per-element slope-gradient term tensor before reducing it, which at
+    1024 frames of 224x224 x 128 channels is a 26 GB transient next to five live tensors of that size; in chunks of
+    ``max_bytes`` it is bounded, and the slope gradient is the sum of the chunk results (fixed order)."""
+    n = dy.shape[0]
+    per = dy[0].numel() * 4
+    step = max(1, min(n, max_bytes // max(per, 1)))
+    if step >= n:
+        return ops.prelu_bwd(dy, x, alpha)
+    dx, da = torch.empty_like(dy), None
+    for i in range(0, n, step):
+        d, a = ops.prelu_bwd(dy[i:i + step], x[i:i + step], alpha)
+        dx[i:i + step] = d
+        da = a if da is None else da + a
+    return dx, da
+
+
 def _bn_affine_from_saved(save_mean, save_invstd, gamma, beta):
     scale = save_invstd * gamma
     return scale.contiguous(), (beta - save_mean * scale).contiguous()
@@ -121,10 +138,13 @@ class _ReleasedUnit(torch.autograd.Function):
 
     ``memory == "recompute"`` (``IR50.activation_memory``, what BASELINE configs[1] at B = 32 x 32 frames of 224x224 needs:
     stage 1 of this IR-50 runs at the full 224x224, so even the raw tensors are 410 MB per frame = 420 GB per step): a unit
-    keeps only its INPUT, as one fp16 plane (2 bytes per element: 62 MB per frame, 64 GB per step), and the backward runs the
-    unit's two convs again from it with the saved batch statistics -- one extra forward of the encoder per step (+1/3 of
-    the conv work) for 6.6x less activation memory.  The rounding of the saved input to fp16 (2^-11 relative) enters the
-    gradients at that level (tests/test_head_release_gpu.py states the bar); forward results are unchanged."""
+    keeps only its INPUT (125 MB per frame, 128 GB per step) and the backward runs the unit's two convs again from it with
+    the saved batch statistics -- one extra forward of the encoder per step (+1/3 of the conv work) for 3.3x less
+    activation memory.  The kernels are deterministic, so the rebuilt tensors and hence all gradients are BIT-IDENTICAL to
+    the "raw" plan (tested).  ``"recompute16"`` halves that again by keeping the input normalised by its first BatchNorm as
+    one fp16 plane (62 MB per frame); the 2^-11 rounding of that plane reaches the gradients amplified like every other
+    per-operation error of this 24-unit batch-statistics backward (~20x: 1e-2 on the whole-encoder gradient against 2.6e-3)
+    -- an explicit trade, held to its own bar in tests/test_head_release_gpu.py."""
 
     @staticmethod
     def forward(ctx, x, u, prec, memory, g1, b1, w1, a1, w2, g2, b2, ws, gs, bs):
@@ -132,10 +152,12 @@ class _ReleasedUnit(torch.autograd.Function):
         bn1, bn2, s = u.res_layer[0], u.res_layer[4], u.stride
         xb, sm1, si1 = ops.bn_rows_fwd(x.view(-1, cin), g1.detach(), b1.detach(), bn1.running_mean, bn1.running_var, True,
                                        bn1.eps, bn1.momentum)
-        xb = xb.view(n, h, w, cin)
-        b3 = prec == "bf16x3"
-        xb_k = ops.split_bf16(xb) if b3 else xb
         del xb
+        b3 = prec == "bf16x3"
+        # BN1(x) as ONE affine pass from the saved statistics -- the same arithmetic the backward uses to rebuild it, so the
+        # "recompute" memory plan reproduces z1 / z2 bit for bit
+        sc1, sh1 = _bn_affine_from_saved(sm1, si1, g1.detach(), b1.detach())
+        xb_k = ops.split_bf16(x, sc1, sh1) if b3 else torch.addcmul(sh1, x, sc1)
         z1 = _conv_prec(xb_k, ops.pack_conv_weight(w1.detach().contiguous()), 3, 3, 1, (1, 1), prec)
         del xb_k
         t1 = ops.prelu_fwd(z1, a1.detach().contiguous())
@@ -156,8 +178,15 @@ class _ReleasedUnit(torch.autograd.Function):
             ops.add_inplace(out, sc.view(n, ho, wo, depth))
         else:
             ops.add_inplace(out, x[:, ::s, ::s].contiguous() if s > 1 else x)  # MaxPool2d(1, s) == subsample
-        if memory == "recompute":   # keep ONE 16-bit plane of the unit input; z1 / z2 / zs are rebuilt from it in the backward
-            xk, z1, z2, zs = x.to(torch.float16), None, None, None
+        if memory == "recompute":      # keep the unit input only; z1 / z2 / zs are rebuilt from it in the backward (bit-identical)
+            xk, z1, z2, zs = x, None, None, None
+        elif memory == "recompute16":
+            # keep ONE 16-bit plane of the unit input; z1 / z2 / zs are rebuilt from it in the backward.  What is kept is the
+            # NORMALISED input (x - mean) * invstd of BatchNorm 1 -- zero mean, unit variance per channel, so fp16's 2^-11 is an
+            # absolute 5e-4 on O(1) values -- not x itself: the residual stream's mean is many standard deviations wide after a
+            # few units, and rounding x would cost the BatchNorm backward's x_hat that factor in accuracy (measured: 1.1e-2
+            # on the whole-encoder gradient against 2.6e-3 with fp32 tensors)
+            xk, z1, z2, zs = ops.to_n16(x, torch.float16, si1, (-sm1 * si1).contiguous()), None, None, None
         else:
             xk = x
         ctx.save_for_backward(xk, z1, z2, sm1, si1, sm2, si2, zs, sms, sis, g1.detach(), b1.detach(), w1.detach(),
@@ -178,16 +207,21 @@ class _ReleasedUnit(torch.autograd.Function):
         # own Trainer has no scaler, so the data-gradient convs of an fp16 encoder run on the bf16x3 kernels (fp32 range,
         # 2^-15 per product) -- scaled or not, nothing underflows.
         dprec = "bf16x3" if prec == "fp16" else prec
-        n, h, w, cin = x.shape
+        n, h, w, cin = x.shape              # (the saved tensor: x, or its normalised fp16 plane -- same shape)
         _, ho, wo, depth = ctx.out_shape
         dout = dout.contiguous()
         b3 = prec != "fp32"   # the weight gradients follow the convs onto the bf16x3 matrix-core kernel
         split = prec == "bf16x3"   # operands split once per tensor, shared by the weight and the data gradient
-        sc1, sh1 = _bn_affine_from_saved(sm1, si1, g1, b1)
         recompute = z2 is None
-        if recompute:              # "recompute" memory plan: the unit's forward again, with the SAVED batch statistics
-            x = x.float()
-        xb = ops.split_bf16(x, sc1, sh1) if split else torch.addcmul(sh1, x, sc1)   # BN1(x) (and split) in one pass
+        xh = None
+        if recompute and x.dtype == torch.float16:   # "recompute16": the saved plane is the normalised input; BN1(x) = xh * gamma + beta
+            xh = ops.from_n16(x)
+            sc1, sh1 = g1.contiguous(), b1.contiguous()
+            xb = ops.split_bf16(xh, sc1, sh1) if split else torch.addcmul(sh1, xh, sc1)
+            x = torch.addcmul(sm1, xh, 1.0 / si1) if ws is not None else None       # only the projection shortcut reads x itself
+        else:
+            sc1, sh1 = _bn_affine_from_saved(sm1, si1, g1, b1)
+            xb = ops.split_bf16(x, sc1, sh1) if split else torch.addcmul(sh1, x, sc1)   # BN1(x) (and split) in one pass
         if recompute:
             z1 = _conv_prec(xb, ops.pack_conv_weight(w1.contiguous()), 3, 3, 1, (1, 1), prec)
         t1 = ops.prelu_fwd(z1, a1.contiguous())                 # recomputed conv input (see the class docstring)
@@ -206,7 +240,7 @@ class _ReleasedUnit(torch.autograd.Function):
         del t1
         dt1 = _conv_dgrad(dz2, w2, s, 1, (h, w), dprec)
         del dz2
-        dz1, da1 = ops.prelu_bwd(dt1, z1, a1.contiguous())
+        dz1, da1 = _prelu_bwd_chunked(dt1, z1, a1.contiguous())
         del dt1, z1
         if split:
             dz1 = ops.split_bf16(dz1)
@@ -215,7 +249,12 @@ class _ReleasedUnit(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         dxb = _conv_dgrad(dz1, w1, 1, 1, (h, w), dprec)
         del dz1
-        dx, dg1, db1 = ops.bn_rows_bwd(dxb.view(-1, cin), x.view(-1, cin), sm1, si1, g1)
+        if xh is not None:   # x_hat is what was saved: mean 0, invstd 1, and the outer gamma * invstd factor as the "weight"
+            dx, dg1, db1 = ops.bn_rows_bwd(dxb.view(-1, cin), xh.view(-1, cin), torch.zeros_like(sm1), torch.ones_like(si1),
+                                           (g1 * si1).contiguous())
+            del xh
+        else:
+            dx, dg1, db1 = ops.bn_rows_bwd(dxb.view(-1, cin), x.view(-1, cin), sm1, si1, g1)
         del dxb
         dx = dx.view(n, h, w, cin)
         dws = dgs = dbs = None
@@ -825,7 +864,7 @@ class IR50(nn.Module):
         return _ReleasedStem.apply(x, il[1], il[0].weight, il[1].weight, il[1].bias, il[2].weight)
 
     def _released_unit(self, u, y, prec="fp32"):
-        if self.activation_memory not in ("raw", "recompute"):
+        if self.activation_memory not in ("raw", "recompute", "recompute16"):
             raise ValueError(f"unknown activation_memory {self.activation_memory!r}")
         pr = u.res_layer
         sc = u.shortcut_layer if u.cin != u.depth else None
