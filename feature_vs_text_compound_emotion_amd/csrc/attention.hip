@@ -13,6 +13,13 @@
 //   O^T += V^T P^T: B[k = key][j = query] is exactly register r of S^T's accumulator when the
 //                   A operand V^T[d][key] is read with the same (register, lane-half) -> key map.
 // Everything is exact fp32 (v_mfma_f32_32x32x2_f32) with full-precision expf.
+//
+// SPLIT variants (round 3): when (Sq / 128) * H * B blocks cannot cover the chip -- the JMT / MT final stage is 1024 tokens x
+// 6 stacks x 1 head = 48 blocks on 256 CUs -- the four waves of a block share the SAME 32 owner rows and split the streamed
+// range between them (tile t goes to wave t % 4, each wave stages its own tiles in its own LDS region), so the grid has
+// four times the blocks; the waves' partial results are merged in LDS in the fixed order wave 0..3 (forward: the usual
+// flash rescale by exp(m_w - m); backward: plain sums, P is recomputed from the saved LSE) -- deterministic, no atomics,
+// no second launch.
 #include <math.h>
 
 #include "cer_internal.h"
@@ -34,17 +41,18 @@ struct AttnArgs {
     float scale;
 };
 
-template <int D>
+template <int D, bool SPLIT>
 __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs p) {
     constexpr int KP = D + 4;   // K tile pitch: conflict-free ds_read_b128 over 16 keys
     constexpr int NG = D / 8;   // 8-wide k groups of the QK^T reduction
     constexpr int NT = D / 32;  // 32-row tiles of O^T
-    __shared__ __attribute__((aligned(16))) float Ks[32 * KP];
-    __shared__ __attribute__((aligned(16))) float Vs[32 * D];
+    constexpr int TILE = 32 * KP + 32 * D;      // floats of one K + V tile pair
+    extern __shared__ __attribute__((aligned(16))) float attn_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *Ks = attn_smem + (SPLIT ? wave * TILE : 0), *Vs = Ks + 32 * KP;
     const int l31 = lane & 31, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
-    const int query = blockIdx.x * 128 + wave * 32 + l31;
+    const int query = SPLIT ? blockIdx.x * 32 + l31 : blockIdx.x * 128 + wave * 32 + l31;
     const bool qok = query < p.Sq;
 
     // Q fragment (B operand of K Q^T), pre-scaled: lane half `half` holds dk = 8g + 4*half + e
@@ -68,10 +76,13 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs p) {
     const float *vbase = p.v + b * p.v_sb + h * p.v_sh;
     const int *mbase = p.key_mask ? p.key_mask + (size_t)b * p.Sk : nullptr;
 
-    for (int k0 = 0; k0 < p.Sk; k0 += 32) {
+    // SPLIT: wave w takes tiles w, w + 4, ... (uniform trip count; tiles past the end are fully masked)
+    const int kstep = SPLIT ? 128 : 32;
+    for (int kb = 0; kb < p.Sk; kb += kstep) {
+        const int k0 = SPLIT ? kb + 32 * wave : kb;
         __syncthreads();  // previous tile fully consumed
         // stage K and V tiles: 32 keys x D floats each, float4 per thread per pass
-        for (int i = tid; i < 32 * (D / 4); i += 256) {
+        for (int i = SPLIT ? lane : tid; i < 32 * (D / 4); i += SPLIT ? 64 : 256) {
             const int key = i / (D / 4), c4 = (i - key * (D / 4)) * 4;
             float4 kv = make_float4(0, 0, 0, 0), vv = make_float4(0, 0, 0, 0);
             if (k0 + key < p.Sk) {
@@ -130,6 +141,40 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs p) {
                 o[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[key * D + 32 * t + l31], s[r], o[t], 0, 0, 0);
         }
     }
+    if constexpr (SPLIT) {
+        // merge the four waves' (m, l, O) in the fixed order 0..3; partials live where the tiles were: [wave][j][lane]
+        __syncthreads();
+        float *part = attn_smem + wave * TILE;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[(t * 16 + r) * 64 + lane] = o[t][r];
+        part[NT * 16 * 64 + lane] = m_run;
+        part[(NT * 16 + 1) * 64 + lane] = l_run;
+        __syncthreads();
+        if (wave != 0) return;
+        float m = m_run;
+#pragma unroll
+        for (int w = 1; w < 4; ++w) m = fmaxf(m, attn_smem[w * TILE + NT * 16 * 64 + lane]);
+        float l = 0.f;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[t][r] = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            const float *pw = attn_smem + w * TILE;
+            const float mw = pw[NT * 16 * 64 + lane];
+            const float sc = (mw == -INFINITY) ? 0.f : expf(mw - m);
+            l += pw[(NT * 16 + 1) * 64 + lane] * sc;
+#pragma unroll
+            for (int t = 0; t < NT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[t][r] += pw[(t * 16 + r) * 64 + lane] * sc;
+        }
+        m_run = m;
+        l_run = l;
+    }
     if (!qok) return;
     if (p.lse && half == 0) p.lse[((size_t)b * p.H + h) * p.Sq + query] = l_run > 0.f ? m_run + logf(l_run) : INFINITY;
     const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
@@ -179,17 +224,19 @@ __global__ void attn_delta_kernel(const float *__restrict__ out, const float *__
     if (lane == 0) delta[row] = s;
 }
 
-template <int D, bool DKV>
+template <int D, bool DKV, bool SPLIT>
 __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(AttnBwdArgs p) {
     constexpr int KP = D + 4, NG = D / 8, NT = D / 32;
-    __shared__ __attribute__((aligned(16))) float T1[32 * KP];  // streamed tile 1 (K or Q), pitch KP
-    __shared__ __attribute__((aligned(16))) float T2[32 * KP];  // streamed tile 2 (V or dO)
-    __shared__ float sl[32], sd[32];                            // DKV: LSE / Delta of the streamed queries
+    constexpr int TILE = 2 * 32 * KP + 64;                      // floats of one (T1, T2, sl, sd) set
+    extern __shared__ __attribute__((aligned(16))) float attn_smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float *T1 = attn_smem + (SPLIT ? wave * TILE : 0);          // streamed tile 1 (K or Q), pitch KP
+    float *T2 = T1 + 32 * KP;                                   // streamed tile 2 (V or dO)
+    float *sl = T2 + 32 * KP, *sd = sl + 32;                    // DKV: LSE / Delta of the streamed queries
     const int l31 = lane & 31, half = lane >> 5;
     const int b = blockIdx.z, h = blockIdx.y;
     const int So = DKV ? p.Sk : p.Sq, Ss = DKV ? p.Sq : p.Sk;  // owner / streamed lengths
-    const int orow = blockIdx.x * 128 + wave * 32 + l31;
+    const int orow = SPLIT ? blockIdx.x * 32 + l31 : blockIdx.x * 128 + wave * 32 + l31;
     const bool ook = orow < So;
     const float *o1 = DKV ? p.k + b * p.k_sb + h * p.k_sh : p.q + b * p.q_sb + h * p.q_sh;
     const float *o2 = DKV ? p.v + b * p.v_sb + h * p.v_sh : p.dout + b * p.o_sb + h * p.o_sh;
@@ -222,9 +269,11 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(AttnBwdArgs p) {
             if constexpr (DKV) accB[t][r] = 0.f;
         }
 
-    for (int t0 = 0; t0 < Ss; t0 += 32) {
+    const int sstep = SPLIT ? 128 : 32;
+    for (int tb = 0; tb < Ss; tb += sstep) {
+        const int t0 = SPLIT ? tb + 32 * wave : tb;
         __syncthreads();
-        for (int i = tid; i < 32 * (D / 4); i += 256) {
+        for (int i = SPLIT ? lane : tid; i < 32 * (D / 4); i += SPLIT ? 64 : 256) {
             const int row = i / (D / 4), c4 = (i - row * (D / 4)) * 4;
             float4 a = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
             if (t0 + row < Ss) {
@@ -234,10 +283,11 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(AttnBwdArgs p) {
             *reinterpret_cast<float4 *>(&T1[row * KP + c4]) = a;
             *reinterpret_cast<float4 *>(&T2[row * KP + c4]) = c;
         }
-        if (DKV && tid < 32) {
-            const bool ok = t0 + tid < p.Sq;
-            sl[tid] = ok ? lse[t0 + tid] : INFINITY;
-            sd[tid] = ok ? delta[t0 + tid] : 0.f;
+        if (DKV && (SPLIT ? lane : tid) < 32) {
+            const int j = SPLIT ? lane : tid;
+            const bool ok = t0 + j < p.Sq;
+            sl[j] = ok ? lse[t0 + j] : INFINITY;
+            sd[j] = ok ? delta[t0 + j] : 0.f;
         }
         __syncthreads();
         f32x16 s, dp;
@@ -285,6 +335,33 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(AttnBwdArgs p) {
             }
         }
     }
+    if constexpr (SPLIT) {
+        // sum the four waves' partial gradients in the fixed order 0..3 (partials stored where the tiles were)
+        __syncthreads();
+        float *pa = attn_smem + wave * TILE, *pb = pa + 32 * KP;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                pa[(t * 16 + r) * 64 + lane] = accA[t][r];
+                if constexpr (DKV) pb[(t * 16 + r) * 64 + lane] = accB[t][r];
+            }
+        __syncthreads();
+        if (wave != 0) return;
+#pragma unroll
+        for (int t = 0; t < NT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float a = 0.f, c = 0.f;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    a += attn_smem[w * TILE + (t * 16 + r) * 64 + lane];
+                    if constexpr (DKV) c += attn_smem[w * TILE + 32 * KP + (t * 16 + r) * 64 + lane];
+                }
+                accA[t][r] = a;
+                if constexpr (DKV) accB[t][r] = c;
+            }
+    }
     if (!ook) return;
     // accA = (DQ: dQ^T | DKV: dK^T), accB = dV^T; layout [d][owner row]
     float *oa = DKV ? p.dk + b * p.dk_sb + (long long)orow * p.dk_ss + h * p.dk_sh
@@ -312,6 +389,26 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(AttnBwdArgs p) {
 
 using namespace cer;
 
+// the four waves of a block share their owner rows and split the streamed range when the plain grid ((rows / 128) * H * B
+// blocks) would leave more than half of the 256 CUs idle and there are enough streamed tiles to split
+static bool attn_use_split(int owner_rows, int streamed_rows, int H, int B) {
+    const long long blocks = (long long)((owner_rows + 127) / 128) * H * B;
+    return blocks < 128 && streamed_rows >= 128;
+}
+
+template <int D, bool SPLIT>
+static int launch_attn_fwd(const AttnArgs &a, hipStream_t st) {
+    constexpr int TILE = 32 * (D + 4) + 32 * D;
+    // SPLIT: four private tile pairs; they are reused for the partial results (D / 2 floats per lane + m + l)
+    const size_t lds = (size_t)(SPLIT ? 4 * TILE : TILE) * sizeof(float);
+    static_assert(!SPLIT || TILE >= (D / 2 + 2) * 64, "partials must fit the tile region");
+    auto k = attention_fwd_kernel<D, SPLIT>;
+    if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const dim3 grid(SPLIT ? (a.Sq + 31) / 32 : (a.Sq + 127) / 128, a.H, a.B);
+    CER_LAUNCH(k, grid, dim3(256), lds, st, a);
+    return CER_OK;
+}
+
 extern "C" int cer_attention_fwd(const float *q, const float *k, const float *v, const int *key_mask, float *out,
                                  float *lse, int B, int H, int Sq, int Sk, int D, const long long *q_strides,
                                  const long long *k_strides, const long long *v_strides, const long long *o_strides,
@@ -329,19 +426,34 @@ extern "C" int cer_attention_fwd(const float *q, const float *k, const float *v,
     a.v_sb = v_strides[0]; a.v_ss = v_strides[1]; a.v_sh = v_strides[2];
     a.o_sb = o_strides[0]; a.o_ss = o_strides[1]; a.o_sh = o_strides[2];
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.scale = scale;
-    dim3 grid((Sq + 127) / 128, H, B);
-    if (D == 64) CER_LAUNCH(attention_fwd_kernel<64>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else if (D == 128) CER_LAUNCH(attention_fwd_kernel<128>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else if (D == 32) CER_LAUNCH(attention_fwd_kernel<32>, grid, dim3(256), 0, (hipStream_t)stream, a);
-    else return cer_set_error(CER_ERR_UNSUPPORTED, "attention_fwd: head dim must be 32, 64 or 128");
+    if (D != 32 && D != 64 && D != 128) return cer_set_error(CER_ERR_UNSUPPORTED, "attention_fwd: head dim must be 32, 64 or 128");
+    const bool split = attn_use_split(Sq, Sk, H, B);
+    int rc;
+    if (D == 32) rc = split ? launch_attn_fwd<32, true>(a, (hipStream_t)stream) : launch_attn_fwd<32, false>(a, (hipStream_t)stream);
+    else if (D == 64) rc = split ? launch_attn_fwd<64, true>(a, (hipStream_t)stream) : launch_attn_fwd<64, false>(a, (hipStream_t)stream);
+    else rc = split ? launch_attn_fwd<128, true>(a, (hipStream_t)stream) : launch_attn_fwd<128, false>(a, (hipStream_t)stream);
+    if (rc != CER_OK) return rc;
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }
 
+template <int D, bool DKV, bool SPLIT>
+static int launch_attn_bwd_one(const AttnBwdArgs &a, hipStream_t st) {
+    constexpr int TILE = 2 * 32 * (D + 4) + 64;
+    static_assert(!SPLIT || 32 * (D + 4) >= (D / 2) * 64, "a partial gradient must fit one tile");
+    const size_t lds = (size_t)(SPLIT ? 4 * TILE : TILE) * sizeof(float);
+    auto k = attention_bwd_kernel<D, DKV, SPLIT>;
+    if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const int owner = DKV ? a.Sk : a.Sq;
+    CER_LAUNCH(k, dim3(SPLIT ? (owner + 31) / 32 : (owner + 127) / 128, a.H, a.B), dim3(256), lds, st, a);
+    return CER_OK;
+}
+
 template <int D>
-static void launch_attn_bwd(const AttnBwdArgs &a, hipStream_t st) {
-    CER_LAUNCH((attention_bwd_kernel<D, false>), dim3((a.Sq + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
-    CER_LAUNCH((attention_bwd_kernel<D, true>), dim3((a.Sk + 127) / 128, a.H, a.B), dim3(256), 0, st, a);
+static int launch_attn_bwd(const AttnBwdArgs &a, hipStream_t st) {
+    int rc = attn_use_split(a.Sq, a.Sk, a.H, a.B) ? launch_attn_bwd_one<D, false, true>(a, st) : launch_attn_bwd_one<D, false, false>(a, st);
+    if (rc != CER_OK) return rc;
+    return attn_use_split(a.Sk, a.Sq, a.H, a.B) ? launch_attn_bwd_one<D, true, true>(a, st) : launch_attn_bwd_one<D, true, false>(a, st);
 }
 
 extern "C" int cer_attention_bwd(const float *q, const float *k, const float *v, const float *out, const float *dout,
@@ -372,9 +484,8 @@ extern "C" int cer_attention_bwd(const float *q, const float *k, const float *v,
     a.dk_sb = dk_strides[0]; a.dk_ss = dk_strides[1]; a.dk_sh = dk_strides[2];
     a.dv_sb = dv_strides[0]; a.dv_ss = dv_strides[1]; a.dv_sh = dv_strides[2];
     a.B = B; a.H = H; a.Sq = Sq; a.Sk = Sk; a.scale = scale;
-    if (D == 32) launch_attn_bwd<32>(a, st);
-    else if (D == 64) launch_attn_bwd<64>(a, st);
-    else launch_attn_bwd<128>(a, st);
+    const int rc = D == 32 ? launch_attn_bwd<32>(a, st) : D == 64 ? launch_attn_bwd<64>(a, st) : launch_attn_bwd<128>(a, st);
+    if (rc != CER_OK) return rc;
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }

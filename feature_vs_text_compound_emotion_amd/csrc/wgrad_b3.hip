@@ -297,6 +297,152 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
         }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Wide variant (round 3) for the 256- / 512-channel layers: output tile 256 couts x 256 cins of one tap, 8 waves (2 cout halves
+// x 4 cin quarters, wave = 128 x 64 = 8 x 4 MFMA tiles).  The 128 x 128 kernel above is bound by what it pulls from L2 into LDS:
+// 32 KiB per K step for 192 MFMAs -- 8 TB/s chip-wide at its measured 0.31 of the bf16x3 ceiling (PMC: MFMA busy 32 %, 36 % of
+// the wave cycles waiting on vmcnt / the barrier), half of what gather-to-LDS loops reach on this part.  Doubling both tile
+// edges moves 64 KiB per step for 768 MFMAs (half the bytes per MFMA) and does twice the MFMA work per barrier.
+// LDS: 8 planes of [32 pixels][128 channels] per stage (dZ hi / lo x 2 cout halves, X hi / lo x 2 cin halves; the swizzle of
+// wg_off per plane), two stages = 128 KiB, one block of 8 waves per CU.  A wave issues ONE 1-KiB piece of every plane per
+// step (its 4 pixel rows), so it tracks a single (n, ho, wo) position.  Register budget at 2 waves per SIMD (<= 256): 128
+// accumulators + the 4 X fragment pairs of the step (32) + one dZ fragment pair at a time (8, the compiler double-buffers).
+template <int DUMMY>
+__global__ __launch_bounds__(512, 1) void conv2d_wgrad_b3_wide_kernel(Wgrad2dArgs p) {
+    constexpr int KS = 32, PLANE = KS * 256, STAGE = 8 * PLANE, TS = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wi = wave & 1, wj = wave >> 1;                     // cout half (= dZ plane), cin quarter
+    const int kg = lane >> 4, l15 = lane & 15;
+    const int per = p.tiles * p.KHW;
+    const int xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int split = (j / per) * 8 + xcd, within = j % per;
+    if (split >= p.splits) return;
+    const int tile = within % p.tiles, tap = within / p.tiles, kh = tap / p.KW, kw = tap - kh * p.KW;
+    const int tiles_ci = (p.Cin + TS - 1) / TS;
+    const int co0 = (tile / tiles_ci) * TS, ci0 = (tile % tiles_ci) * TS;
+    const int r_begin = split * p.rows_per_split;
+    const int r_end = min(p.R, r_begin + p.rows_per_split);
+    const int hw = p.Ho * p.Wo;
+
+    const int q4 = l15 >> 2, p4 = l15 & 3;
+    int tr_a[8][2], tr_b[4][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int row = 8 * kg + 4 * h + q4;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) tr_a[t][h] = wg_off(row, 2 * t + (p4 >> 1)) + 8 * (p4 & 1);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) tr_b[t][h] = wg_off(row, 2 * ((wj & 1) * 4 + t) + (p4 >> 1)) + 8 * (p4 & 1);
+    }
+    auto frag = [&](const unsigned char *plane, const int off[2]) {
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(plane + off[0]));
+        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)(plane + off[1]));
+        const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return v;
+    };
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[a][b][r] = 0.f;
+
+    constexpr unsigned OOB = 0x80000000u;
+    const int drow = lane >> 4, dch = lane & 15;
+    const int rl = 4 * wave + drow;                               // this lane's pixel row inside a step
+    const int ch = dch ^ (((rl & 3) << 2) | ((rl >> 2) & 3));     // source chunk (8 channels) for this LDS slot
+    int dn, dho, dwo;
+    {
+        const int r = r_begin + rl;
+        dn = r / hw;
+        const int q = r - dn * hw;
+        dho = q / p.Wo;
+        dwo = q - dho * p.Wo;
+    }
+    const int adv_h = KS / p.Wo, adv_w = KS - adv_h * p.Wo;
+    auto issue_step = [&](int r0, int buf) {
+        const int n0 = __builtin_amdgcn_readfirstlane(r0 / hw);
+        const size_t zb = (size_t)r0 * p.Cout * 2, xb = (size_t)n0 * p.H * p.W * p.Cin * 2;
+        const __amdgpu_buffer_rsrc_t rzh = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.dz_hi)) + zb, 0, (int)OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rzl = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.dz_lo)) + zb, 0, (int)OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rxh = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.x_hi)) + xb, 0, (int)OOB, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rxl = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(reinterpret_cast<const char *>(p.x_lo)) + xb, 0, (int)OOB, 0x00020000);
+        const int r = r0 + rl;
+        const int hi = dho * p.stride - p.pad_t + kh, wi_ = dwo * p.stride - p.pad_l + kw;
+        const bool live = r < r_end;
+        const bool xpix = live && (unsigned)hi < (unsigned)p.H && (unsigned)wi_ < (unsigned)p.W;
+        const size_t xrow = (((size_t)(dn - n0) * p.H + hi) * p.W + wi_) * p.Cin;
+        unsigned char *dst = smem_w + buf * STAGE + wave * 1024;
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            const int co = co0 + pl * 128 + ch * 8, ci = ci0 + pl * 128 + ch * 8;
+            const unsigned ao = (live && co < p.Cout) ? (unsigned)(((size_t)rl * p.Cout + co) * 2) : OOB;
+            const unsigned bo = (xpix && ci < p.Cin) ? (unsigned)((xrow + ci) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rzh, (lds_ptr_t)(dst + (0 + pl) * PLANE), 16, (int)ao, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rzl, (lds_ptr_t)(dst + (2 + pl) * PLANE), 16, (int)ao, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxh, (lds_ptr_t)(dst + (4 + pl) * PLANE), 16, (int)bo, 0, 0, 0);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rxl, (lds_ptr_t)(dst + (6 + pl) * PLANE), 16, (int)bo, 0, 0, 0);
+        }
+        dwo += adv_w;
+        dho += adv_h;
+        if (dwo >= p.Wo) {
+            dwo -= p.Wo;
+            ++dho;
+        }
+        while (dho >= p.Ho) {
+            dho -= p.Ho;
+            ++dn;
+        }
+    };
+
+    const int steps = (r_end - r_begin + KS - 1) / KS;
+    if (steps > 0) {
+        issue_step(r_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    for (int s = 0; s < steps; ++s) {
+        const int buf = s & 1;
+        if (s + 1 < steps) issue_step(r_begin + (s + 1) * KS, buf ^ 1);
+        const unsigned char *base = smem_w + buf * STAGE;
+        const unsigned char *zh = base + wi * PLANE, *zl = base + (2 + wi) * PLANE;
+        const unsigned char *xh = base + (4 + (wj >> 1)) * PLANE, *xl = base + (6 + (wj >> 1)) * PLANE;
+        s16x8 bh[4], bl[4];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            bh[t] = frag(xh, tr_b[t]);
+            bl[t] = frag(xl, tr_b[t]);
+        }
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            const s16x8 ah = frag(zh, tr_a[a]), al = frag(zl, tr_a[a]);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(al), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah), as_bf16(bl[b]), acc[a][b], 0, 0, 0);
+#pragma unroll
+            for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+    float *out = p.out + (size_t)split * p.Cout * p.Cin * p.KHW;
+#pragma unroll
+    for (int a = 0; a < 8; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int ci = ci0 + wj * 64 + b * 16 + l15;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int co = co0 + wi * 128 + a * 16 + 4 * kg + r;
+                if (co < p.Cout && ci < p.Cin) out[((size_t)co * p.Cin + ci) * p.KHW + tap] = acc[a][b][r];
+            }
+        }
+}
+
 __global__ void wgrad_reduce_kernel(const float4 *__restrict__ part, float4 *__restrict__ dw, size_t n4, int splits) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n4) return;
@@ -308,9 +454,10 @@ __global__ void wgrad_reduce_kernel(const float4 *__restrict__ part, float4 *__r
     dw[i] = s;
 }
 
-static int wgrad_b3_splits(long long R, int tiles, int taps) {
-    // enough blocks for two waves of 512 resident blocks, at least 8 K steps each
-    long long s = (1024 + (long long)tiles * taps - 1) / ((long long)tiles * taps);
+static int wgrad_b3_splits(long long R, int tiles, int taps, int ts = 128) {
+    // enough blocks for two waves of 512 resident blocks (wide tile: 256, one block per CU), at least 8 K steps each
+    const long long want = ts == 256 ? 512 : 1024;
+    long long s = (want + (long long)tiles * taps - 1) / ((long long)tiles * taps);
     s = (s + 7) / 8 * 8;   // one split per XCD and round (see the kernel's work order)
     const long long max_s = (R + 255) / 256;
     if (s > max_s) s = max_s;
@@ -321,14 +468,24 @@ static int wgrad_b3_splits(long long R, int tiles, int taps) {
 
 using namespace cer;
 
-// 64 x 64 tiles when a 128-wide tile would be at most half full on either side
-static int wgrad_b3_tile(int Cout, int Cin) { return (Cout <= 64 || Cin <= 64) ? 64 : 128; }
+// 64 x 64 tiles when a 128-wide tile would be at most half full on either side; 256 x 256 (the wide kernel: split operands
+// only) when both channel counts fill it
+static int wgrad_b3_tile(int Cout, int Cin, bool split_in = false) {
+    if (split_in && Cout % 256 == 0 && Cin % 256 == 0) return 256;
+    return (Cout <= 64 || Cin <= 64) ? 64 : 128;
+}
 
 extern "C" size_t cer_conv2d_wgrad_b3_workspace_bytes(int N, int Ho, int Wo, int Cout, int Cin, int KH, int KW) {
     if (N <= 0 || Ho <= 0 || Wo <= 0 || Cout <= 0 || Cin <= 0 || KH <= 0 || KW <= 0) return 0;
-    const int ts = wgrad_b3_tile(Cout, Cin);
-    const int splits = wgrad_b3_splits((long long)N * Ho * Wo, ((Cout + ts - 1) / ts) * ((Cin + ts - 1) / ts), KH * KW);
-    return splits > 1 ? (size_t)splits * Cout * Cin * KH * KW * sizeof(float) : 0;
+    // (the split-operand entry point may pick the wide tile, which needs fewer splits: size for the larger of the two)
+    size_t need = 0;
+    for (int pass = 0; pass < 2; ++pass) {
+        const int ts = wgrad_b3_tile(Cout, Cin, pass == 1);
+        const int splits = wgrad_b3_splits((long long)N * Ho * Wo, ((Cout + ts - 1) / ts) * ((Cin + ts - 1) / ts), KH * KW, ts);
+        const size_t b = splits > 1 ? (size_t)splits * Cout * Cin * KH * KW * sizeof(float) : 0;
+        need = b > need ? b : need;
+    }
+    return need;
 }
 
 static int wgrad_b3_run(const float *dz, const float *x, const uint16_t *dz_hi, const uint16_t *dz_lo, const uint16_t *x_hi,
@@ -340,9 +497,10 @@ static int wgrad_b3_run(const float *dz, const float *x, const uint16_t *dz_hi, 
         return cer_set_error(CER_ERR_INVALID_ARG, "conv2d_wgrad_b3: bad argument");
     if ((Cout & 3) || (Cin & 3))
         return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d_wgrad_b3: Cout and Cin must be multiples of 4 (use cer_conv2d_wgrad)");
-    const int ts = wgrad_b3_tile(Cout, Cin);
+    int ts = wgrad_b3_tile(Cout, Cin, split_in);
+    if (ts == 256 && !((long long)(32 + 2ll * H * W) * Cin * 2 < (1ll << 31) && 32ll * Cout * 2 < (1ll << 31))) ts = 128;
     const int R = N * Ho * Wo, tiles = ((Cout + ts - 1) / ts) * ((Cin + ts - 1) / ts), taps = KH * KW;
-    const int splits = wgrad_b3_splits(R, tiles, taps);
+    const int splits = wgrad_b3_splits(R, tiles, taps, ts);
     const size_t n = (size_t)Cout * Cin * taps;
     if (splits > 1 && (!workspace || workspace_bytes < (size_t)splits * n * sizeof(float)))
         return cer_set_error(CER_ERR_WORKSPACE, "conv2d_wgrad_b3: workspace too small");
@@ -351,7 +509,12 @@ static int wgrad_b3_run(const float *dz, const float *x, const uint16_t *dz_hi, 
     a.rows_per_split = ((R + splits - 1) / splits + 31) / 32 * 32;
     const dim3 grid((unsigned)((splits + 7) / 8 * 8 * tiles * taps));
     hipStream_t st = (hipStream_t)stream;
-    if (ts == 64) {
+    if (ts == 256) {
+        constexpr int lds = 2 * 8 * 32 * 256;
+        auto k = conv2d_wgrad_b3_wide_kernel<0>;
+        CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+        CER_LAUNCH(k, grid, dim3(512), lds, st, a);
+    } else if (ts == 64) {
         if (split_in) CER_LAUNCH((conv2d_wgrad_b3_kernel<64, true>), grid, dim3(256), 0, st, a);
         else CER_LAUNCH((conv2d_wgrad_b3_kernel<64, false>), grid, dim3(256), 0, st, a);
     } else {

@@ -64,7 +64,11 @@ def test_vggish_matches_reference_fixture_and_oracle(precision):
     assert (got - ref).abs().max().item() < 1e-4 * max(1.0, ref.abs().max().item())
 
 
-@pytest.mark.parametrize("b,h,sq,sk,d", [(2, 3, 40, 40, 64), (1, 1, 200, 200, 128), (3, 2, 33, 70, 32), (1, 12, 256, 256, 64)])
+@pytest.mark.parametrize("b,h,sq,sk,d", [(2, 3, 40, 40, 64), (1, 1, 200, 200, 128), (3, 2, 33, 70, 32), (1, 12, 256, 256, 64),
+                                         # few owner blocks, long streams: the split variants (four waves share 32 owner rows
+                                         # and split the streamed tiles; tile counts that do and do not divide by 4, ragged
+                                         # ends, a stream shorter than one tile per wave)
+                                         (6, 1, 1024, 1024, 128), (1, 1, 300, 517, 128), (2, 2, 70, 130, 64), (1, 1, 37, 160, 32)])
 def test_attention_kernel_vs_torch(b, h, sq, sk, d):
     from feature_vs_text_compound_emotion_amd import ops
     g = torch.Generator().manual_seed(b * 100 + sq)
@@ -148,7 +152,9 @@ def test_feature_extractor_matches_oracle_composition():
         assert (out["bert"][b, 0].cpu() - ref).abs().max().item() < 2e-4
 
 
-@pytest.mark.parametrize("b,h,sq,sk,d", [(2, 1, 40, 40, 128), (1, 2, 70, 33, 64), (3, 1, 200, 200, 128), (2, 2, 32, 96, 32)])
+@pytest.mark.parametrize("b,h,sq,sk,d", [(2, 1, 40, 40, 128), (1, 2, 70, 33, 64), (3, 1, 200, 200, 128), (2, 2, 32, 96, 32),
+                                         # split variants: dQ splits the keys, dK / dV split the queries
+                                         (6, 1, 1024, 1024, 128), (1, 1, 300, 517, 128), (2, 2, 130, 70, 64), (1, 1, 160, 37, 32)])
 def test_attention_backward_vs_torch_autograd(b, h, sq, sk, d):
     from feature_vs_text_compound_emotion_amd import ops
     g = torch.Generator().manual_seed(b * 7 + sq)

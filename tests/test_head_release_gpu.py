@@ -325,6 +325,9 @@ def test_whole_encoder_backward_vs_float64_oracle(precision, with_stem, n, hw, m
     # stride-2 data gradient as four parity convs: odd sizes (the 5 -> 3 layer of the 40x40 crop), narrow storage
     (6, 256, 512, 5, 3, 2, "bf16x3"), (4, 64, 64, 9, 3, 2, "bf16x3"), (4, 128, 128, 10, 3, 2, "fp16"), (4, 64, 128, 7, 3, 2, "bf16"),
     (5, 128, 256, 7, 1, 2, "bf16x3"),
+    # the 256 x 256-tile weight-gradient kernel (8 waves, both channel counts multiples of 256): one / several tiles per tap,
+    # a row count that is not a multiple of the 32-pixel step, stride 2, 1x1
+    (40, 256, 256, 10, 3, 1, "bf16x3"), (21, 512, 512, 5, 3, 1, "bf16x3"), (33, 256, 512, 8, 1, 2, "bf16x3"),
     # the 224x224 geometry bench.py --release 4 --hw 224 times (round-2 verdict: parity-tested at 40x40 only): 6.4 M / 1.6 M pixel
     # rows per weight-gradient reduction, patch-kernel data gradients (H, W % 16 == 0), the stride-2 layers of units 1 and 4
     (2, 64, 64, 224, 3, 1, "bf16x3"), (2, 64, 64, 224, 3, 2, "bf16x3"), (2, 128, 128, 112, 3, 2, "bf16x3"),
@@ -355,7 +358,11 @@ def test_conv2d_wgrad_b3_and_dgrad_in_the_encoder_precision(n, cin, cout, hw, k,
     assert (err <= bound).all(), (err / bound).max().item()
     # operands that are split tensors already (what the released units keep): the same arithmetic, no conversion in the loader
     dw_s = ops.conv2d_wgrad(ops.split_bf16(dz), ops.split_bf16(xd), k, k, stride=stride, pad=(k // 2, k // 2), b3=True)
-    assert torch.equal(dw_s, dw)
+    if cin % 256 == 0 and cout % 256 == 0:   # split operands of this width take the 256 x 256 tile: another summation order
+        err = (dw_s.cpu().double() - w.grad).abs()
+        assert (err <= bound).all(), (err / bound).max().item()
+    else:
+        assert torch.equal(dw_s, dw)
     ref_fp32 = ops.conv2d_wgrad(dz, xd, k, k, stride=stride, pad=(k // 2, k // 2))          # the fp32-MFMA kernel agrees
     assert (ref_fp32.cpu().double() - w.grad).abs().max().item() < 1e-3 * max(1.0, w.grad.abs().max().item())
     dx = _conv_dgrad(dz, w.detach().float().cuda(), stride, k // 2, (hw, hw), prec)
