@@ -414,7 +414,9 @@ class Workload:
                 a["flops"] += fl
                 a["ms"] += e0.elapsed_time(e1)
             for kind, a in att.items():
-                a["kernel"] = f"cer::attention_{kind}_kernel<128> (exact fp32 MFMA, flash style)"
+                a["kernel"] = f"cer::attention_{kind.split('_')[0]}_kernel<128> (exact fp32 MFMA, flash style" + \
+                    (f"; the {kind.split('_')[1]}-token launches: cfg3's final stage, split-stream variant)" if "_" in kind else
+                     "; the per-clip launches: 32 tokens x 32 clips, latency-bound by size)")
                 a["achieved"] = a["flops"] / (a["ms"] * 1e-3) / 1e12
                 a["peak"], a["unit"], a["bound"] = FP32_MFMA_PEAK_TFLOPS, "TFLOP/s", "mfma"
                 a["frac"] = a["achieved"] / FP32_MFMA_PEAK_TFLOPS
@@ -557,9 +559,9 @@ def main():
         for kn, kv in ro.get("all_kernels", {}).items():
             if kn.startswith("cer::conv_n16_patch_kernel<64"):
                 flat[f"{tag}_patch64_frac"] = kv["frac"]
-        for kind in ("fwd", "bwd"):
-            if kind in ro.get("attention", {}):
-                flat[f"{tag}_attention_{kind}_frac"] = ro["attention"][kind]["frac"]
+        for kind, av in ro.get("attention", {}).items():
+            if isinstance(av, dict) and "frac" in av:
+                flat[f"{tag}_attention_{kind}_frac"] = av["frac"]
     if rank == 0:
         res["roofline"].update(flat)
         out = {"metric": "training clips/sec (32-frame tri-modal clip)", "value": res["value"], "unit": "clips/s",

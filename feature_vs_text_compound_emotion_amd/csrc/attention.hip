@@ -78,21 +78,35 @@ __global__ __launch_bounds__(256) void attention_fwd_kernel(AttnArgs p) {
 
     // SPLIT: wave w takes tiles w, w + 4, ... (uniform trip count; tiles past the end are fully masked)
     const int kstep = SPLIT ? 128 : 32;
+    // K / V tiles travel global -> registers -> LDS; the NEXT tile's loads are issued before the current tile's MFMAs, so
+    // their latency (one wave per SIMD: nothing else would cover it) runs under ~128 matrix instructions
+    constexpr int NLD = 32 * (D / 4) / (SPLIT ? 64 : 256);      // float4 per lane, tile and operand
+    float4 pk[NLD], pv[NLD];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) {
+            const int i = (SPLIT ? lane : tid) + n * (SPLIT ? 64 : 256);
+            const int key = i / (D / 4), c4 = (i - key * (D / 4)) * 4;
+            pk[n] = pv[n] = make_float4(0, 0, 0, 0);
+            if (k0 + key < p.Sk) {
+                pk[n] = *reinterpret_cast<const float4 *>(kbase + (long long)(k0 + key) * p.k_ss + c4);
+                pv[n] = *reinterpret_cast<const float4 *>(vbase + (long long)(k0 + key) * p.v_ss + c4);
+            }
+        }
+    };
+    fetch(SPLIT ? 32 * wave : 0);
     for (int kb = 0; kb < p.Sk; kb += kstep) {
         const int k0 = SPLIT ? kb + 32 * wave : kb;
         __syncthreads();  // previous tile fully consumed
-        // stage K and V tiles: 32 keys x D floats each, float4 per thread per pass
-        for (int i = SPLIT ? lane : tid; i < 32 * (D / 4); i += SPLIT ? 64 : 256) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) {
+            const int i = (SPLIT ? lane : tid) + n * (SPLIT ? 64 : 256);
             const int key = i / (D / 4), c4 = (i - key * (D / 4)) * 4;
-            float4 kv = make_float4(0, 0, 0, 0), vv = make_float4(0, 0, 0, 0);
-            if (k0 + key < p.Sk) {
-                kv = *reinterpret_cast<const float4 *>(kbase + (long long)(k0 + key) * p.k_ss + c4);
-                vv = *reinterpret_cast<const float4 *>(vbase + (long long)(k0 + key) * p.v_ss + c4);
-            }
-            *reinterpret_cast<float4 *>(&Ks[key * KP + c4]) = kv;
-            *reinterpret_cast<float4 *>(&Vs[key * D + c4]) = vv;
+            *reinterpret_cast<float4 *>(&Ks[key * KP + c4]) = pk[n];
+            *reinterpret_cast<float4 *>(&Vs[key * D + c4]) = pv[n];
         }
         __syncthreads();
+        if (kb + kstep < p.Sk) fetch(k0 + kstep);
 
         // S^T tile = K Q^T
         f32x16 s;
@@ -270,18 +284,46 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(AttnBwdArgs p) {
         }
 
     const int sstep = SPLIT ? 128 : 32;
+    constexpr int NLD = 32 * (D / 4) / (SPLIT ? 64 : 256);      // float4 per lane, tile and operand (prefetched one tile ahead)
+    float4 pa[NLD], pc[NLD];
+    auto fetch = [&](int t0) {
+#pragma unroll
+        for (int n = 0; n < NLD; ++n) {
+            const int i = (SPLIT ? lane : tid) + n * (SPLIT ? 64 : 256);
+            const int row = i / (D / 4), c4 = (i - row * (D / 4)) * 4;
+            pa[n] = pc[n] = make_float4(0, 0, 0, 0);
+            if (t0 + row < Ss) {
+                pa[n] = *reinterpret_cast<const float4 *>(s1 + (long long)(t0 + row) * s1s + c4);
+                pc[n] = *reinterpret_cast<const float4 *>(s2 + (long long)(t0 + row) * s2s + c4);
+            }
+        }
+    };
+    // (split variant at d = 128: owner fragments 128 + accumulators 128-192 registers leave no room for 128 more of prefetch
+    // -- the compiler spilled 47 registers -- so there the tile is fetched where it is used)
+    constexpr bool PF = !(SPLIT && D == 128);
+    if constexpr (PF) fetch(SPLIT ? 32 * wave : 0);
     for (int tb = 0; tb < Ss; tb += sstep) {
         const int t0 = SPLIT ? tb + 32 * wave : tb;
         __syncthreads();
-        for (int i = SPLIT ? lane : tid; i < 32 * (D / 4); i += SPLIT ? 64 : 256) {
-            const int row = i / (D / 4), c4 = (i - row * (D / 4)) * 4;
-            float4 a = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
-            if (t0 + row < Ss) {
-                a = *reinterpret_cast<const float4 *>(s1 + (long long)(t0 + row) * s1s + c4);
-                c = *reinterpret_cast<const float4 *>(s2 + (long long)(t0 + row) * s2s + c4);
+        if constexpr (PF) {
+#pragma unroll
+            for (int n = 0; n < NLD; ++n) {
+                const int i = (SPLIT ? lane : tid) + n * (SPLIT ? 64 : 256);
+                const int row = i / (D / 4), c4 = (i - row * (D / 4)) * 4;
+                *reinterpret_cast<float4 *>(&T1[row * KP + c4]) = pa[n];
+                *reinterpret_cast<float4 *>(&T2[row * KP + c4]) = pc[n];
             }
-            *reinterpret_cast<float4 *>(&T1[row * KP + c4]) = a;
-            *reinterpret_cast<float4 *>(&T2[row * KP + c4]) = c;
+        } else {
+            for (int i = SPLIT ? lane : tid; i < 32 * (D / 4); i += SPLIT ? 64 : 256) {
+                const int row = i / (D / 4), c4 = (i - row * (D / 4)) * 4;
+                float4 a = make_float4(0, 0, 0, 0), c = make_float4(0, 0, 0, 0);
+                if (t0 + row < Ss) {
+                    a = *reinterpret_cast<const float4 *>(s1 + (long long)(t0 + row) * s1s + c4);
+                    c = *reinterpret_cast<const float4 *>(s2 + (long long)(t0 + row) * s2s + c4);
+                }
+                *reinterpret_cast<float4 *>(&T1[row * KP + c4]) = a;
+                *reinterpret_cast<float4 *>(&T2[row * KP + c4]) = c;
+            }
         }
         if (DKV && (SPLIT ? lane : tid) < 32) {
             const int j = SPLIT ? lane : tid;
@@ -290,6 +332,9 @@ __global__ __launch_bounds__(256, 1) void attention_bwd_kernel(AttnBwdArgs p) {
             sd[j] = ok ? delta[t0 + j] : 0.f;
         }
         __syncthreads();
+        if constexpr (PF) {
+            if (tb + sstep < Ss) fetch(t0 + sstep);
+        }
         f32x16 s, dp;
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }

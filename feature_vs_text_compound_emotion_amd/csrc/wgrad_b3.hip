@@ -254,26 +254,29 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
             if (s + 1 < steps) load_step(r_begin + (s + 1) * KS);
         }
         const unsigned char *base = smem + buf * STAGE;
-        s16x8 ah[NTW], al[NTW], bh[NTW], bl[NTW];
+        s16x8 bh[NTW], bl[NTW];
 #pragma unroll
         for (int t = 0; t < NTW; ++t) {
-            ah[t] = frag(base, tr_a[t]);
-            al[t] = frag(base + PLANE, tr_a[t]);
             bh[t] = frag(base + 2 * PLANE, tr_b[t]);
             bl[t] = frag(base + 3 * PLANE, tr_b[t]);
         }
 #pragma unroll
-        for (int a = 0; a < NTW; ++a)
+        for (int a = 0; a < NTW; ++a) {
+            const s16x8 ah = frag(base, tr_a[a]), al = frag(base + PLANE, tr_a[a]);
 #pragma unroll
-            for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(al[a]), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
+            for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(al), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
 #pragma unroll
-        for (int a = 0; a < NTW; ++a)
+            for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah), as_bf16(bl[b]), acc[a][b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah[a]), as_bf16(bl[b]), acc[a][b], 0, 0, 0);
+            for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
+        }
+        // issue order (round 3): X fragments + the first dZ pair, then the reads of pair a + 1 in front of the MFMAs of pair a
+        __builtin_amdgcn_sched_group_barrier(0x100, 4 * NTW + 4, 0);
 #pragma unroll
-        for (int a = 0; a < NTW; ++a)
-#pragma unroll
-            for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah[a]), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
+        for (int a = 0; a < NTW; ++a) {
+            if (a + 1 < NTW) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NTW, 0);
+        }
         if constexpr (DMA) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the next stage has landed
         } else {
@@ -426,6 +429,15 @@ __global__ __launch_bounds__(512, 1) void conv2d_wgrad_b3_wide_kernel(Wgrad2dArg
 #pragma unroll
             for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
         }
+        // issue order: the X fragments and the first dZ pair, then the reads of pair a + 1 in front of the 12 MFMAs of pair a
+        // (left to itself the scheduler hoists all 48 reads to the top: every wave of the block -- they leave the barrier
+        // together -- then reads while no matrix pipe works, and multiplies while the LDS idles)
+        __builtin_amdgcn_sched_group_barrier(0x100, 16 + 4, 0);
+#pragma unroll
+        for (int a = 0; a < 8; ++a) {
+            if (a + 1 < 8) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 12, 0);
+        }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
     }
@@ -455,13 +467,27 @@ __global__ void wgrad_reduce_kernel(const float4 *__restrict__ part, float4 *__r
 }
 
 static int wgrad_b3_splits(long long R, int tiles, int taps, int ts = 128) {
-    // enough blocks for two waves of 512 resident blocks (wide tile: 256, one block per CU), at least 8 K steps each
-    const long long want = ts == 256 ? 512 : 1024;
-    long long s = (want + (long long)tiles * taps - 1) / ((long long)tiles * taps);
-    s = (s + 7) / 8 * 8;   // one split per XCD and round (see the kernel's work order)
+    // The pixel range is cut into `s` splits; s * tiles * taps blocks run in rounds of `slots` resident blocks (2 per CU; the
+    // wide tile: 1 per CU), each block walking R / s / 32 K steps, and a reduce kernel adds the s partial slabs.  Pick the
+    // s that minimises rounds x steps (+ the reduce's share): e.g. 256 -> 256 @56x56, wide tile: 9 blocks per split --
+    // "enough blocks for two rounds" took s = 64 = 576 blocks = 2.25 -> THREE rounds of 1568 steps; s = 56 = 504 blocks runs
+    // two rounds of 1792 (-24 %).
+    const long long per = (long long)tiles * taps, slots = ts == 256 ? 256 : 512;
     const long long max_s = (R + 255) / 256;
-    if (s > max_s) s = max_s;
-    return (int)(s < 1 ? 1 : s);
+    long long best = 1;
+    double best_cost = 1e300;
+    for (long long s = 1; s <= max_s && s <= 4096; ++s) {
+        const long long rows = ((R + s - 1) / s + 31) / 32 * 32, steps = rows / 32;
+        if (steps < 8 && s > 1) break;
+        const long long rounds = (s * per + slots - 1) / slots;
+        // a K step of a resident block costs ~1 unit; the reduce reads s slabs of the output: ~ s * (outputs / bytes-per-step-unit)
+        const double cost = (double)rounds * (steps + 24) + 0.02 * (double)s;
+        if (cost < best_cost) {
+            best_cost = cost;
+            best = s;
+        }
+    }
+    return (int)best;
 }
 
 }  // namespace cer

@@ -1084,7 +1084,7 @@ def attention(q, k, v, out, batch, heads, sq, sk, d, q_strides, k_strides, v_str
                                         current_stream()), "cer_attention_fwd")
     if ATTN_TRACE is not None:
         e1.record()
-        ATTN_TRACE.append(("fwd", 4.0 * batch * heads * sq * sk * d, e0, e1))
+        ATTN_TRACE.append(("fwd" if sq * sk < (1 << 18) else f"fwd_{sq}x{sk}", 4.0 * batch * heads * sq * sk * d, e0, e1))
     return out
 
 
@@ -1106,7 +1106,7 @@ def attention_bwd(q, k, v, out, dout, lse, dq, dk, dv, batch, heads, sq, sk, d, 
           "cer_attention_bwd")
     if ATTN_TRACE is not None:
         e1.record()
-        ATTN_TRACE.append(("bwd", 8.0 * batch * heads * sq * sk * d, e0, e1))
+        ATTN_TRACE.append(("bwd" if sq * sk < (1 << 18) else f"bwd_{sq}x{sk}", 8.0 * batch * heads * sq * sk * d, e0, e1))
 
 
 def add_inplace(y, x):
