@@ -654,7 +654,8 @@ extern "C" int cer_bn_rows_fwd(const float *x, int x_ld, const float *w, const f
                                float *running_var, float *save_mean, float *save_invstd, float *y, int y_ld, int R,
                                int C, int train, float eps, float momentum, void *workspace, size_t workspace_bytes,
                                void *stream) {
-    if (!x || !w || !b || !y || R <= 0 || C <= 0 || x_ld < C || y_ld < C || !running_mean || !running_var)
+    // y == NULL (train mode only): statistics pass alone -- save_mean / save_invstd and the running-buffer update, no output
+    if (!x || R <= 0 || C <= 0 || x_ld < C || !running_mean || !running_var || (y ? (!w || !b || y_ld < C) : !train))
         return cer_set_error(CER_ERR_INVALID_ARG, "bn_rows_fwd: bad argument");
     const size_t n = (size_t)R * C;
     if (train) {
@@ -671,8 +672,9 @@ extern "C" int cer_bn_rows_fwd(const float *x, int x_ld, const float *w, const f
             CER_LAUNCH(bn_rows_stats_kernel, dim3((C + 31) / 32), dim3(256), 0, ST, x, x_ld, save_mean, save_invstd,
                                running_mean, running_var, R, C, eps, momentum);
         }
-        CER_LAUNCH(bn_rows_apply_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, ST, x, x_ld,
-                           (const float *)save_mean, (const float *)save_invstd, 0, eps, w, b, y, y_ld, R, C);
+        if (y)
+            CER_LAUNCH(bn_rows_apply_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, ST, x, x_ld,
+                               (const float *)save_mean, (const float *)save_invstd, 0, eps, w, b, y, y_ld, R, C);
     } else {
         CER_LAUNCH(bn_rows_apply_kernel, dim3(cer_blocks(n, 256)), dim3(256), 0, ST, x, x_ld,
                            (const float *)running_mean, (const float *)running_var, 1, eps, w, b, y, y_ld, R, C);

@@ -479,7 +479,10 @@ static int wgrad_b3_splits(long long R, int tiles, int taps, int ts = 128) {
     for (long long s = 1; s <= max_s && s <= 4096; ++s) {
         const long long rows = ((R + s - 1) / s + 31) / 32 * 32, steps = rows / 32;
         if (steps < 8 && s > 1) break;
-        const long long rounds = (s * per + slots - 1) / slots;
+        // the kernel deals the splits round-robin over the 8 XCDs (split = 8 * (j / per) + xcd, so the blocks of a split
+        // share one L2): an XCD holds ceil(s / 8) * per blocks for its slots / 8 places -- s = 28 with 9 blocks per split is
+        // 36 blocks on four 32-CU XCDs = TWO rounds, not the one that 252 blocks / 256 places suggests (measured: 2x)
+        const long long rounds = (((s + 7) / 8) * per + slots / 8 - 1) / (slots / 8);
         // a K step of a resident block costs ~1 unit; the reduce reads s slabs of the output: ~ s * (outputs / bytes-per-step-unit)
         const double cost = (double)rounds * (steps + 24) + 0.02 * (double)s;
         if (cost < best_cost) {

@@ -862,6 +862,21 @@ def bn_rows_fwd(x, w, b, running_mean, running_var, train, eps=1e-5, momentum=0.
     return out, sm, si
 
 
+def bn_rows_stats(x, running_mean, running_var, eps=1e-5, momentum=0.1):
+    """Train-mode statistics of the rows of x [R,C] alone: (save_mean, save_invstd), running buffers updated in place like
+    ``bn_rows_fwd(train=True)``; no output tensor is written."""
+    r, c, x_ld = _rows(x, "x")
+    _dev_f32(running_mean, "running_mean")
+    _dev_f32(running_var, "running_var")
+    sm, si = _empty((c,), x), _empty((c,), x)
+    lib = _lib.load()
+    nbytes = lib.cer_bn_rows_fwd_workspace_bytes(r, c)
+    ws = _empty((nbytes // 4,), x) if nbytes else None
+    check(lib.cer_bn_rows_fwd(ptr(x), x_ld, None, None, ptr(running_mean), ptr(running_var), ptr(sm), ptr(si), None, 0, r, c, 1,
+                              eps, momentum, ptr(ws), nbytes, current_stream()), "cer_bn_rows_fwd")
+    return sm, si
+
+
 def bn_rows_bwd(dy, x, save_mean, save_invstd, w, train=True):
     r, c, dy_ld = _rows(dy, "dy")
     _, _, x_ld = _rows(x, "x")

@@ -119,6 +119,16 @@ def _prelu_bwd_chunked(dy, x, alpha, max_bytes=4 << 30):
     return dx, da
 
 
+_ZERO_B9 = {}
+
+
+def _zero_bias9(cout, device):
+    key = (cout, str(device))
+    if key not in _ZERO_B9:
+        _ZERO_B9[key] = torch.zeros((9, cout), device=device, dtype=torch.float32)
+    return _ZERO_B9[key]
+
+
 def _bn_affine_from_saved(save_mean, save_invstd, gamma, beta):
     scale = save_invstd * gamma
     return scale.contiguous(), (beta - save_mean * scale).contiguous()
@@ -150,34 +160,40 @@ class _ReleasedUnit(torch.autograd.Function):
     def forward(ctx, x, u, prec, memory, g1, b1, w1, a1, w2, g2, b2, ws, gs, bs):
         n, h, w, cin = x.shape
         bn1, bn2, s = u.res_layer[0], u.res_layer[4], u.stride
-        xb, sm1, si1 = ops.bn_rows_fwd(x.view(-1, cin), g1.detach(), b1.detach(), bn1.running_mean, bn1.running_var, True,
-                                       bn1.eps, bn1.momentum)
-        del xb
         b3 = prec == "bf16x3"
-        # BN1(x) as ONE affine pass from the saved statistics -- the same arithmetic the backward uses to rebuild it, so the
-        # "recompute" memory plan reproduces z1 / z2 bit for bit
+        # BatchNorm 1: statistics pass only; the normalisation is ONE affine (+ split) pass from them -- the same arithmetic the
+        # backward uses to rebuild it, so the "recompute" memory plan reproduces z1 / z2 bit for bit
+        sm1, si1 = ops.bn_rows_stats(x.view(-1, cin), bn1.running_mean, bn1.running_var, bn1.eps, bn1.momentum)
         sc1, sh1 = _bn_affine_from_saved(sm1, si1, g1.detach(), b1.detach())
         xb_k = ops.split_bf16(x, sc1, sh1) if b3 else torch.addcmul(sh1, x, sc1)
-        z1 = _conv_prec(xb_k, ops.pack_conv_weight(w1.detach().contiguous()), 3, 3, 1, (1, 1), prec)
-        del xb_k
-        t1 = ops.prelu_fwd(z1, a1.detach().contiguous())
-        t1_k = ops.split_bf16(t1) if b3 else t1
-        del t1
+        if b3 and memory != "raw":   # z1 is not kept: PReLU and the split happen in the conv's epilogue (no z1 / t1 round trips)
+            z1 = None
+            # (a zero border-bias table selects the straight-line "bias9 + PReLU -> split" row epilogue of the window kernels)
+            t1_k = ops.conv2d_b3(xb_k, ops.split_bf16(ops.pack_conv_weight(w1.detach().contiguous())), 3, 3, pad=(1, 1),
+                                 bias9=_zero_bias9(w1.shape[0], x.device), alpha=a1.detach().contiguous(),
+                                 act1=ops.ACT_PRELU)["split"]
+            del xb_k
+        else:
+            z1 = _conv_prec(xb_k, ops.pack_conv_weight(w1.detach().contiguous()), 3, 3, 1, (1, 1), prec)
+            del xb_k
+            t1 = ops.prelu_fwd(z1, a1.detach().contiguous())
+            t1_k = ops.split_bf16(t1) if b3 else t1
+            del t1
         z2 = _conv_prec(t1_k, ops.pack_conv_weight(w2.detach().contiguous()), 3, 3, s, (1, 1), prec)
         del t1_k
         _, ho, wo, depth = z2.shape
-        out, sm2, si2 = ops.bn_rows_fwd(z2.view(-1, depth), g2.detach(), b2.detach(), bn2.running_mean, bn2.running_var, True,
-                                        bn2.eps, bn2.momentum)
-        out = out.view(n, ho, wo, depth)
+        # BatchNorm 2 (+ the shortcut's BatchNorm) and the residual add in ONE pass over z2: statistics, then scale / shift
+        sm2, si2 = ops.bn_rows_stats(z2.view(-1, depth), bn2.running_mean, bn2.running_var, bn2.eps, bn2.momentum)
+        sc2, sh2 = _bn_affine_from_saved(sm2, si2, g2.detach(), b2.detach())
         zs = sms = sis = None
         if ws is not None:
             bns = u.shortcut_layer[1]
             zs = _conv_prec(x, ops.pack_conv_weight(ws.detach().contiguous()), 1, 1, s, (0, 0), prec)
-            sc, sms, sis = ops.bn_rows_fwd(zs.view(-1, depth), gs.detach(), bs.detach(), bns.running_mean, bns.running_var, True,
-                                           bns.eps, bns.momentum)
-            ops.add_inplace(out, sc.view(n, ho, wo, depth))
+            sms, sis = ops.bn_rows_stats(zs.view(-1, depth), bns.running_mean, bns.running_var, bns.eps, bns.momentum)
+            scs, shs = _bn_affine_from_saved(sms, sis, gs.detach(), bs.detach())
+            out = ops.bn_apply_nhwc(z2, sc2, sh2, res=zs, res_scale=scs, res_shift=shs)
         else:
-            ops.add_inplace(out, x[:, ::s, ::s].contiguous() if s > 1 else x)  # MaxPool2d(1, s) == subsample
+            out = ops.bn_apply_nhwc(z2, sc2, sh2, res=x, res_stride=s)   # MaxPool2d(1, s) == subsample
         if memory == "recompute":      # keep the unit input only; z1 / z2 / zs are rebuilt from it in the backward (bit-identical)
             xk, z1, z2, zs = x, None, None, None
         elif memory == "recompute16":

@@ -280,6 +280,9 @@ int cer_tblock_tail_bwd(const float *dout, const float *out, const float *a2, co
  * running stats updated in place (unbiased variance, `momentum`), save_mean/save_invstd written.
  * train == 0: running statistics. */
 size_t cer_bn_rows_fwd_workspace_bytes(int R, int C);   /* 0 for R <= 2048; larger R reduce the statistics in two column sums */
+/* y == NULL with train != 0: statistics pass alone (save_mean / save_invstd, running buffers updated), nothing is written --
+ * the released encoder units apply the normalisation inside the pass that follows (affine + split, or cer_bn_apply_nhwc
+ * with the shortcut add), so the separate apply pass over the activation would be read-once-write-once traffic for nothing. */
 int cer_bn_rows_fwd(const float *x, int x_ld, const float *w, const float *b, float *running_mean,
                     float *running_var, float *save_mean, float *save_invstd, float *y, int y_ld,
                     int R, int C, int train, float eps, float momentum, void *workspace, size_t workspace_bytes, void *stream);
