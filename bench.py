@@ -97,13 +97,18 @@ def measured_traffic(cfg, kernel=None):
     (tools/collect_traffic.py: FETCH_SIZE x2 + WRITE_SIZE, separate passes, gfx950 corrections).  PMC counters cannot be read
     from inside the timed process, so the value is looked up -- by configuration AND by the hash of the kernel sources the
     profile was taken on: a profile of other code is not reported (null)."""
-    path = os.path.join(ROOT, "profiles", f"round2_traffic_{cfg['precision']}_hw{cfg['hw']}_L{cfg['length']}.json")
-    try:
-        t = json.load(open(path))
-    except (OSError, ValueError):
-        return None
-    if (str(t.get("batch")), str(t.get("length")), t.get("encoders"), t.get("kernel_source_sha")) != \
-            (str(cfg["batch"]), str(cfg["length"]), cfg["encoders"], kernel_source_sha()):
+    t = None
+    for rnd in ("round3", "round2"):     # the newest profile taken on THESE kernel sources
+        path = os.path.join(ROOT, "profiles", f"{rnd}_traffic_{cfg['precision']}_hw{cfg['hw']}_L{cfg['length']}.json")
+        try:
+            c = json.load(open(path))
+        except (OSError, ValueError):
+            continue
+        if (str(c.get("batch")), str(c.get("length")), c.get("encoders"), c.get("kernel_source_sha")) == \
+                (str(cfg["batch"]), str(cfg["length"]), cfg["encoders"], kernel_source_sha()):
+            t = c
+            break
+    if t is None or cfg.get("release"):
         return None
     if kernel is not None:  # per launch of one kernel variant, like roofline.achieved
         return t.get("per_kernel", {}).get(kernel, {}).get("hbm_bytes_per_launch")
