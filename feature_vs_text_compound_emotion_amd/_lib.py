@@ -71,6 +71,9 @@ _SIGNATURES = {
     "cer_conv2d_wgrad_b3s": (c_int, [_P, _P, _P, _P, _P] + [c_int] * 12 + [_P, c_size_t, _P]),
     "cer_prelu_fwd": (c_int, [_P, _P, _P, c_size_t, c_int, _P]),
     "cer_prelu_bwd": (c_int, [_P, _P, _P, _P, _P, c_size_t, c_int, _P]),
+    "cer_prelu_split": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),
+    "cer_prelu_bwd_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, _P]),
+    "cer_bn_rows_bwd_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
     "cer_col_sum_workspace_bytes": (c_size_t, [c_int, c_int]),
     "cer_col_sum": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
     "cer_act_mask_bwd": (c_int, [_P, _P, _P, _P, c_size_t, c_float, _P]),

@@ -619,14 +619,35 @@ def prelu_fwd(x, alpha):
     return y
 
 
-def prelu_bwd(dy, x, alpha):
-    """-> (dx, dalpha): torch's PReLU backward for channels-last tensors."""
+def prelu_split(x, alpha):
+    """prelu(x) as a Split tensor in one pass (the conv input a released unit rebuilds from its raw conv result)."""
+    _dev_f32(x, "x")
+    _dev_f32(alpha, "alpha")
+    out = Split.empty(x.shape, x.device)
+    c = x.shape[-1]
+    check(_lib.load().cer_prelu_split(ptr(x), ptr(alpha), ptr(out.hi), ptr(out.lo), x.numel() // c, c, current_stream()),
+          "cer_prelu_split")
+    return out
+
+
+def prelu_bwd(dy, x, alpha, out=None, split_out=False):
+    """-> (dx, dalpha): torch's PReLU backward for channels-last tensors.  ``split_out``: dx comes back as a Split tensor (no fp32
+    copy is written); ``out``: write dx into this fp32 tensor / Split (a slice of a larger one: chunked calls)."""
     for t, nme in ((dy, "dy"), (x, "x"), (alpha, "alpha")):
         _dev_f32(t, nme)
-    dx, terms = torch.empty_like(x), torch.empty_like(x)
+    terms = torch.empty_like(x)
     c = x.shape[-1]
-    check(_lib.load().cer_prelu_bwd(ptr(dy), ptr(x), ptr(alpha), ptr(dx), ptr(terms), x.numel() // c, c, current_stream()),
-          "cer_prelu_bwd")
+    if split_out:
+        dx = out if out is not None else Split.empty(x.shape, x.device)
+        _dev_bf16(dx.hi, "out.hi")
+        _dev_bf16(dx.lo, "out.lo")
+        check(_lib.load().cer_prelu_bwd_split(ptr(dy), ptr(x), ptr(alpha), None, ptr(dx.hi), ptr(dx.lo), ptr(terms), x.numel() // c, c,
+                                              current_stream()), "cer_prelu_bwd_split")
+    else:
+        dx = out if out is not None else torch.empty_like(x)
+        _dev_f32(dx, "out")
+        check(_lib.load().cer_prelu_bwd(ptr(dy), ptr(x), ptr(alpha), ptr(dx), ptr(terms), x.numel() // c, c, current_stream()),
+              "cer_prelu_bwd")
     return dx, col_sum(terms.view(-1, c))
 
 
@@ -877,7 +898,17 @@ def bn_rows_stats(x, running_mean, running_var, eps=1e-5, momentum=0.1):
     return sm, si
 
 
-def bn_rows_bwd(dy, x, save_mean, save_invstd, w, train=True):
+def bn_rows_bwd(dy, x, save_mean, save_invstd, w, train=True, split_out=False):
+    """``split_out`` (train mode, dense rows): dx as a Split tensor written by the apply pass itself."""
+    if split_out:
+        _dev_f32(dy, "dy")
+        _dev_f32(x, "x")
+        r, c = dy.shape
+        dx, dw, db = Split.empty((r, c), x.device), _empty((c,), x), _empty((c,), x)
+        ws, nbytes = _col_ws(r, c, x)
+        check(_lib.load().cer_bn_rows_bwd_split(ptr(dy), ptr(x), ptr(save_mean), ptr(save_invstd), ptr(w), ptr(dx.hi), ptr(dx.lo),
+                                                ptr(dw), ptr(db), r, c, ptr(ws), nbytes, current_stream()), "cer_bn_rows_bwd_split")
+        return dx, dw, db
     r, c, dy_ld = _rows(dy, "dy")
     _, _, x_ld = _rows(x, "x")
     dx, dw, db = _empty((r, c), x), _empty((c,), x), _empty((c,), x)

@@ -102,19 +102,21 @@ def _conv_dgrad(dy, w_oihw, stride, pad, in_hw, prec="fp32"):
     return dx
 
 
-def _prelu_bwd_chunked(dy, x, alpha, max_bytes=4 << 30):
+def _prelu_bwd_chunked(dy, x, alpha, split_out=False, max_bytes=4 << 30):
     """``ops.prelu_bwd`` over frame chunks: the kernel writes a per-element slope-gradient term tensor before reducing it, which at
     1024 frames of 224x224 x 128 channels is a 26 GB transient next to five live tensors of that size; in chunks of
-    ``max_bytes`` it is bounded, and the slope gradient is the sum of the chunk results (fixed order)."""
+    ``max_bytes`` it is bounded, and the slope gradient is the sum of the chunk results (fixed order).  The chunks write
+    straight into slices of the result (fp32, or the Split tensor the weight / data gradient kernels read)."""
     n = dy.shape[0]
     per = dy[0].numel() * 4
     step = max(1, min(n, max_bytes // max(per, 1)))
     if step >= n:
-        return ops.prelu_bwd(dy, x, alpha)
-    dx, da = torch.empty_like(dy), None
+        return ops.prelu_bwd(dy, x, alpha, split_out=split_out)
+    dx = ops.Split.empty(dy.shape, dy.device) if split_out else torch.empty_like(dy)
+    da = None
     for i in range(0, n, step):
-        d, a = ops.prelu_bwd(dy[i:i + step], x[i:i + step], alpha)
-        dx[i:i + step] = d
+        o = ops.Split(dx.hi[i:i + step], dx.lo[i:i + step]) if split_out else dx[i:i + step]
+        _, a = ops.prelu_bwd(dy[i:i + step], x[i:i + step], alpha, out=o, split_out=split_out)
         da = a if da is None else da + a
     return dx, da
 
@@ -240,26 +242,21 @@ class _ReleasedUnit(torch.autograd.Function):
             xb = ops.split_bf16(x, sc1, sh1) if split else torch.addcmul(sh1, x, sc1)   # BN1(x) (and split) in one pass
         if recompute:
             z1 = _conv_prec(xb, ops.pack_conv_weight(w1.contiguous()), 3, 3, 1, (1, 1), prec)
-        t1 = ops.prelu_fwd(z1, a1.contiguous())                 # recomputed conv input (see the class docstring)
-        if split:
-            t1 = ops.split_bf16(t1)
+        # the second conv's input, rebuilt from the raw conv result (see the class docstring); split in the same pass
+        t1 = ops.prelu_split(z1, a1.contiguous()) if split else ops.prelu_fwd(z1, a1.contiguous())
         if recompute:
             z2 = _conv_prec(t1, ops.pack_conv_weight(w2.contiguous()), 3, 3, s, (1, 1), prec)
             if ws is not None:
                 zs = _conv_prec(x, ops.pack_conv_weight(ws.contiguous()), 1, 1, s, (0, 0), prec)
-        dz2, dg2, db2 = ops.bn_rows_bwd(dout.view(-1, depth), z2.view(-1, depth), sm2, si2, g2)
+        dz2, dg2, db2 = ops.bn_rows_bwd(dout.view(-1, depth), z2.view(-1, depth), sm2, si2, g2, split_out=split)
         del z2
         dz2 = dz2.view(n, ho, wo, depth)
-        if split:
-            dz2 = ops.split_bf16(dz2)
         dw2 = ops.conv2d_wgrad(dz2, t1, 3, 3, stride=s, pad=(1, 1), b3=b3)
         del t1
         dt1 = _conv_dgrad(dz2, w2, s, 1, (h, w), dprec)
         del dz2
-        dz1, da1 = _prelu_bwd_chunked(dt1, z1, a1.contiguous())
+        dz1, da1 = _prelu_bwd_chunked(dt1, z1, a1.contiguous(), split_out=split)
         del dt1, z1
-        if split:
-            dz1 = ops.split_bf16(dz1)
         dw1 = ops.conv2d_wgrad(dz1, xb, 3, 3, stride=1, pad=(1, 1), b3=b3)
         del xb
         need_dx = ctx.needs_input_grad[0]

@@ -159,6 +159,19 @@ int cer_to_n16(const float *x, const float *scale, const float *shift, int C, ui
                void *stream);
 int cer_from_n16(const uint16_t *x, float *out, size_t n, int storage, void *stream);
 
+/* Elementwise passes of the released encoder units that hand a SPLIT tensor (hi / lo bf16 planes) straight to the matrix-core
+ * kernels -- replace "torch op -> fp32 tensor -> cer_split_bf16" pairs in the backward of a bottleneck_IR unit
+ * (reference models/arcface_model.py:44-60; PReLU :54, BatchNorm2d :53,57):
+ *   cer_prelu_split        t = prelu(x) -> split
+ *   cer_prelu_bwd_split    torch's PReLU backward; dx as fp32 (dx) and / or split (dx_hi, dx_lo); dalpha_terms as cer_prelu_bwd
+ *   cer_bn_rows_bwd_split  cer_bn_rows_bwd (train mode, dense rows) with dx as a split tensor; workspace as cer_col_sum */
+int cer_prelu_split(const float *x, const float *alpha, uint16_t *hi, uint16_t *lo, size_t rows, int C, void *stream);
+int cer_prelu_bwd_split(const float *dy, const float *x, const float *alpha, float *dx, uint16_t *dx_hi, uint16_t *dx_lo,
+                        float *dalpha_terms, size_t rows, int C, void *stream);
+int cer_bn_rows_bwd_split(const float *dy, const float *x, const float *save_mean, const float *save_invstd, const float *w,
+                          uint16_t *dx_hi, uint16_t *dx_lo, float *dw, float *db, int R, int C, void *workspace,
+                          size_t workspace_bytes, void *stream);
+
 /* v' = v*scale[c]+shift[c] (channels-last, C channels; scale/shift may be NULL) -> (bf16(v'), bf16(v' - bf16(v'))),
  * round-to-nearest-even on both parts. */
 int cer_split_bf16(const float *x, const float *scale, const float *shift, int C, uint16_t *hi, uint16_t *lo, size_t n,

@@ -384,3 +384,37 @@ def test_prelu_fwd_bwd_vs_autograd():
     assert torch.equal(ops.prelu_fwd(x.detach().cuda(), a.detach().cuda()).cpu(), y.detach().reshape(64, 50).t())
     dx, da = ops.prelu_bwd(dy.cuda(), x.detach().cuda(), a.detach().cuda())
     assert (dx.cpu() - x.grad).abs().max().item() < 1e-6 and (da.cpu() - a.grad).abs().max().item() < 1e-4
+
+
+def test_fused_split_passes_equal_the_two_pass_forms():
+    """Round 3: PReLU forward / backward and the BatchNorm backward's apply pass write the Split tensor the matrix-core kernels
+    read in the same pass (cer_prelu_split, cer_prelu_bwd_split, cer_bn_rows_bwd_split).  Same arithmetic as "fp32 result, then
+    cer_split_bf16": the PReLU forms bit for bit, the BatchNorm form to fp32 rounding (the two kernels contract a*b+c differently)."""
+    from feature_vs_text_compound_emotion_amd import ops
+    gen = torch.Generator().manual_seed(12)
+    x = torch.randn(5, 7, 9, 64, generator=gen).cuda()
+    dy = torch.randn(5, 7, 9, 64, generator=gen).cuda()
+    a = (torch.rand(64, generator=gen) * 0.4 - 0.1).cuda()
+    ref = ops.split_bf16(ops.prelu_fwd(x, a))
+    got = ops.prelu_split(x, a)
+    assert torch.equal(got.hi, ref.hi) and torch.equal(got.lo, ref.lo)
+    dx, da = ops.prelu_bwd(dy, x, a)
+    dxs, das = ops.prelu_bwd(dy, x, a, split_out=True)
+    r = ops.split_bf16(dx)
+    assert torch.equal(dxs.hi, r.hi) and torch.equal(dxs.lo, r.lo) and torch.equal(da, das)
+    big = torch.empty(10, 7, 9, 64, device="cuda")     # chunked calls write into slices
+    ops.prelu_bwd(dy, x, a, out=big[5:])
+    assert torch.equal(big[5:], dx)
+    rows, c = 5 * 7 * 9, 64
+    w = (torch.rand(c, generator=gen) + 0.5).cuda()
+    mean, invstd = x.view(rows, c).mean(0), torch.rsqrt(x.view(rows, c).var(0, unbiased=False) + 1e-5)
+    d32, dw, db = ops.bn_rows_bwd(dy.view(rows, c), x.view(rows, c), mean, invstd, w)
+    ds, dws, dbs = ops.bn_rows_bwd(dy.view(rows, c), x.view(rows, c), mean, invstd, w, split_out=True)
+    assert torch.equal(dw, dws) and torch.equal(db, dbs)
+    assert (ds.float() - d32).abs().max().item() < 1e-6 * max(1.0, d32.abs().max().item())
+    # against torch autograd
+    xt = x.view(rows, c).cpu().double().requires_grad_(True)
+    wt = w.cpu().double().requires_grad_(True)
+    y = torch.nn.functional.batch_norm(xt, None, None, wt, torch.zeros(c, dtype=torch.float64), True, 0.0, 1e-5)
+    y.backward(dy.view(rows, c).cpu().double())
+    assert (ds.float().cpu().double() - xt.grad).abs().max().item() < 1e-5
