@@ -411,10 +411,11 @@ def test_fused_split_passes_equal_the_two_pass_forms():
     d32, dw, db = ops.bn_rows_bwd(dy.view(rows, c), x.view(rows, c), mean, invstd, w)
     ds, dws, dbs = ops.bn_rows_bwd(dy.view(rows, c), x.view(rows, c), mean, invstd, w, split_out=True)
     assert torch.equal(dw, dws) and torch.equal(db, dbs)
-    assert (ds.float() - d32).abs().max().item() < 1e-6 * max(1.0, d32.abs().max().item())
+    # a Split carries 16 mantissa bits: compare with the split of the fp32 result (the two differ by fp32 rounding of the inputs)
+    assert (ds.float() - ops.split_bf16(d32).float()).abs().max().item() < 2.0 ** -15 * max(1.0, d32.abs().max().item())
     # against torch autograd
     xt = x.view(rows, c).cpu().double().requires_grad_(True)
     wt = w.cpu().double().requires_grad_(True)
     y = torch.nn.functional.batch_norm(xt, None, None, wt, torch.zeros(c, dtype=torch.float64), True, 0.0, 1e-5)
     y.backward(dy.view(rows, c).cpu().double())
-    assert (ds.float().cpu().double() - xt.grad).abs().max().item() < 1e-5
+    assert (ds.float().cpu().double() - xt.grad).abs().max().item() < 2.0 ** -14 * max(1.0, xt.grad.abs().max().item())
