@@ -546,9 +546,7 @@ extern "C" int cer_bn_rows_bwd_split(const float *dy, const float *x, const floa
                                      void *workspace, size_t workspace_bytes, void *stream) {
     if (!dy || !x || !save_mean || !save_invstd || !w || !dx_hi || !dx_lo || !dw || !db || R <= 0 || C <= 0 || (C & 3))
         return cer_set_error(CER_ERR_INVALID_ARG, "bn_rows_bwd_split: bad argument (dense rows, C % 4 == 0)");
-    int rc = cer_col_sum(dy, C, nullptr, 0, nullptr, nullptr, db, R, C, workspace, workspace_bytes, stream);
-    if (rc) return rc;
-    rc = cer_col_sum(dy, C, x, C, save_mean, save_invstd, dw, R, C, workspace, workspace_bytes, stream);
+    const int rc = cer_bn_bwd_sums(dy, x, save_mean, save_invstd, db, dw, R, C, workspace, workspace_bytes, stream);
     if (rc) return rc;
     const size_t n4 = (size_t)R * (C / 4);
     CER_LAUNCH(bn_rows_bwd_split_kernel, dim3(cer_blocks(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)dy,

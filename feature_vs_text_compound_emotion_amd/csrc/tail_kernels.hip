@@ -139,6 +139,62 @@ __global__ __launch_bounds__(256) void col_sum4_kernel(const float *__restrict__
     }
 }
 
+// TWO column sums in one pass over the rows (round 3: the released encoder units' BatchNorm passes are column sums over
+// 13-26 GB tensors, 8 % of a whole-encoder training step; each of these pairs used to be two passes):
+//   a != NULL:  out1 = sum a,            out2 = sum a * (b - mean) * invstd      (BatchNorm backward: sum dy, sum dy * x_hat)
+//   a == NULL:  out1 = sum (b - mean),   out2 = sum (b - mean)^2                 (batch statistics about the shift `mean`)
+// Same block shape as col_sum4_kernel; partial rows go to out1 / out2 [slab][C].
+__global__ __launch_bounds__(256) void col_sum_pair4_kernel(const float *__restrict__ a, const float *__restrict__ b,
+                                                             const float *__restrict__ mean, const float *__restrict__ invstd,
+                                                             float *__restrict__ out1, float *__restrict__ out2, int R, int C,
+                                                             int rows_per_slab) {
+    __shared__ float red[8][32][8];
+    const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;
+    const int c = (blockIdx.x * 32 + cx) * 4;
+    const int r0 = blockIdx.y * rows_per_slab, r1 = min(R, r0 + rows_per_slab);
+    float s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+    if (c < C) {
+        float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = make_float4(1.f, 1.f, 1.f, 1.f);
+        if (mean) mu = *reinterpret_cast<const float4 *>(mean + c);
+        if (invstd) is = *reinterpret_cast<const float4 *>(invstd + c);
+        for (int r = r0 + ry; r < r1; r += 32) {
+            float4 va[4], vb[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int rr = r + 8 * u;
+                const bool ok = rr < r1;
+                va[u] = (a && ok) ? *reinterpret_cast<const float4 *>(a + (size_t)rr * C + c) : make_float4(0.f, 0.f, 0.f, 0.f);
+                vb[u] = ok ? *reinterpret_cast<const float4 *>(b + (size_t)rr * C + c) : make_float4(mu.x, mu.y, mu.z, mu.w);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const float d[4] = {(vb[u].x - mu.x) * is.x, (vb[u].y - mu.y) * is.y, (vb[u].z - mu.z) * is.z, (vb[u].w - mu.w) * is.w};
+                const float v[4] = {va[u].x, va[u].y, va[u].z, va[u].w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    s1[e] += a ? v[e] : d[e];
+                    s2[e] += a ? v[e] * d[e] : d[e] * d[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[ry][cx][e] = s1[e];
+        red[ry][cx][4 + e] = s2[e];
+    }
+    __syncthreads();
+    if (ry == 0 && c < C) {
+        float t[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) t[e] += red[i][cx][e];
+        *reinterpret_cast<float4 *>(out1 + (size_t)blockIdx.y * C + c) = make_float4(t[0], t[1], t[2], t[3]);
+        *reinterpret_cast<float4 *>(out2 + (size_t)blockIdx.y * C + c) = make_float4(t[4], t[5], t[6], t[7]);
+    }
+}
+
 // ------------------------------------------------------------- TCN glue
 // dz = dy * mask * leaky'(y)   (y = mask * leaky(z): sign(y) == sign(z) wherever mask != 0)
 __global__ void act_mask_bwd_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ y,
@@ -574,7 +630,23 @@ extern "C" int cer_weight_norm_bwd(const float *dw, const float *v, const float 
 
 extern "C" size_t cer_col_sum_workspace_bytes(int R, int C) {
     int slabs = (R + 255) / 256;
-    return slabs > 1 ? (size_t)slabs * C * sizeof(float) : 0;
+    return slabs > 1 ? (size_t)2 * slabs * C * sizeof(float) : 0;   // two partial arrays: the paired sums below
+}
+
+// out1 / out2 = the two column sums of col_sum_pair4_kernel (dense rows, C % 4 == 0, more than one slab); false = not applicable
+static bool col_sum_pair(const float *a, const float *b, const float *mean, const float *invstd, float *out1, float *out2, int R, int C,
+                         void *workspace, size_t workspace_bytes, void *stream) {
+    int rows_per_slab = 256;
+    if ((R + 255) / 256 > 1024) rows_per_slab = ((R + 1023) / 1024 + 31) / 32 * 32;
+    const int slabs = (R + rows_per_slab - 1) / rows_per_slab;
+    if (slabs <= 1 || (C & 3) || !workspace || workspace_bytes < (size_t)2 * slabs * C * sizeof(float)) return false;
+    float *p1 = (float *)workspace, *p2 = p1 + (size_t)slabs * C;
+    CER_LAUNCH(col_sum_pair4_kernel, dim3((C + 127) / 128, slabs), dim3(256), 0, ST, a, b, mean, invstd, p1, p2, R, C, rows_per_slab);
+    CER_LAUNCH(col_sum_kernel, dim3((C + 31) / 32, 1), dim3(256), 0, ST, (const float *)p1, C, (const float *)nullptr, 0,
+               (const float *)nullptr, (const float *)nullptr, out1, slabs, C, slabs);
+    CER_LAUNCH(col_sum_kernel, dim3((C + 31) / 32, 1), dim3(256), 0, ST, (const float *)p2, C, (const float *)nullptr, 0,
+               (const float *)nullptr, (const float *)nullptr, out2, slabs, C, slabs);
+    return true;
 }
 
 extern "C" int cer_col_sum(const float *a, int a_ld, const float *b, int b_ld, const float *mean,
@@ -648,6 +720,22 @@ __global__ void bn_rows_finish_kernel(const float *__restrict__ mean, float *__r
     }
 }
 
+// s1 = sum (x - k), s2 = sum (x - k)^2 with k = running_mean (before its update)  ->  mean, invstd, running buffers
+__global__ void bn_rows_shifted_finish_kernel(float *__restrict__ s1_to_mean, float *__restrict__ s2_to_invstd,
+                                              float *__restrict__ running_mean, float *__restrict__ running_var, int R, int C,
+                                              float eps, float momentum) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double d1 = (double)s1_to_mean[c] / R, d2 = (double)s2_to_invstd[c] / R;
+    double var = d2 - d1 * d1;
+    var = var > 0.0 ? var : 0.0;
+    const float mean = (float)((double)running_mean[c] + d1);
+    s1_to_mean[c] = mean;
+    s2_to_invstd[c] = rsqrtf((float)var + eps);
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)var * (float)R / (float)max(R - 1, 1);
+}
+
 extern "C" size_t cer_bn_rows_fwd_workspace_bytes(int R, int C) { return R > 2048 ? cer_col_sum_workspace_bytes(R, C) : 0; }
 
 extern "C" int cer_bn_rows_fwd(const float *x, int x_ld, const float *w, const float *b, float *running_mean,
@@ -660,7 +748,13 @@ extern "C" int cer_bn_rows_fwd(const float *x, int x_ld, const float *w, const f
     const size_t n = (size_t)R * C;
     if (train) {
         if (!save_mean || !save_invstd) return cer_set_error(CER_ERR_INVALID_ARG, "bn_rows_fwd: train needs save buffers");
-        if (R > 2048) {
+        if (R > 2048 && x_ld == C &&
+            col_sum_pair(nullptr, x, running_mean, nullptr, save_mean, save_invstd, R, C, workspace, workspace_bytes, stream)) {
+            // ONE pass: sum (x - k) and sum (x - k)^2 about the shift k = the running mean (a per-channel constant known before
+            // the pass; any k is exact algebra, a k near the batch mean keeps E[d^2] - E[d]^2 free of cancellation)
+            CER_LAUNCH(bn_rows_shifted_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, save_mean, save_invstd, running_mean,
+                       running_var, R, C, eps, momentum);
+        } else if (R > 2048) {
             int rc = cer_col_sum(x, x_ld, nullptr, 0, nullptr, nullptr, save_mean, R, C, workspace, workspace_bytes, stream);
             if (rc) return rc;
             CER_LAUNCH(bn_rows_mean_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, save_mean, R, C);
@@ -688,10 +782,12 @@ extern "C" int cer_bn_rows_bwd(const float *dy, int dy_ld, const float *x, int x
                                int C, int train, void *workspace, size_t workspace_bytes, void *stream) {
     if (!dy || !x || !save_mean || !save_invstd || !w || !dx || !dw || !db || R <= 0 || C <= 0)
         return cer_set_error(CER_ERR_INVALID_ARG, "bn_rows_bwd: bad argument");
-    int rc = cer_col_sum(dy, dy_ld, nullptr, 0, nullptr, nullptr, db, R, C, workspace, workspace_bytes, stream);
-    if (rc) return rc;
-    rc = cer_col_sum(dy, dy_ld, x, x_ld, save_mean, save_invstd, dw, R, C, workspace, workspace_bytes, stream);
-    if (rc) return rc;
+    if (!(dy_ld == C && x_ld == C && col_sum_pair(dy, x, save_mean, save_invstd, db, dw, R, C, workspace, workspace_bytes, stream))) {
+        int rc = cer_col_sum(dy, dy_ld, nullptr, 0, nullptr, nullptr, db, R, C, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+        rc = cer_col_sum(dy, dy_ld, x, x_ld, save_mean, save_invstd, dw, R, C, workspace, workspace_bytes, stream);
+        if (rc) return rc;
+    }
     CER_LAUNCH(bn_rows_bwd_kernel, dim3(cer_blocks((size_t)R * C, 256)), dim3(256), 0, ST, dy, dy_ld, x, x_ld,
                        save_mean, save_invstd, w, (const float *)db, (const float *)dw, dx, R, C, train);
     CER_HIP_CHECK(hipGetLastError());
@@ -784,4 +880,18 @@ extern "C" int cer_copy_cols(const float *x, int x_ld, float *y, int y_ld, int R
     CER_LAUNCH(copy_cols_kernel, dim3(cer_blocks((size_t)R * C, 256)), dim3(256), 0, ST, x, x_ld, y, y_ld, R, C);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
+}
+
+
+// (used by cer_bn_rows_bwd_split in conv_b3.hip) db = sum dy, dw = sum dy * x_hat in one pass when the shape allows, else two
+extern "C" int cer_bn_bwd_sums(const float *dy, const float *x, const float *save_mean, const float *save_invstd, float *db, float *dw,
+                               int R, int C, void *workspace, size_t workspace_bytes, void *stream) {
+    if (!dy || !x || !save_mean || !save_invstd || !db || !dw || R <= 0 || C <= 0) return cer_set_error(CER_ERR_INVALID_ARG, "bn_bwd_sums: bad argument");
+    if (col_sum_pair(dy, x, save_mean, save_invstd, db, dw, R, C, workspace, workspace_bytes, stream)) {
+        CER_HIP_CHECK(hipGetLastError());
+        return CER_OK;
+    }
+    int rc = cer_col_sum(dy, C, nullptr, 0, nullptr, nullptr, db, R, C, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    return cer_col_sum(dy, C, x, C, save_mean, save_invstd, dw, R, C, workspace, workspace_bytes, stream);
 }

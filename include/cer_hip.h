@@ -279,6 +279,10 @@ int cer_prelu_bwd(const float *dy, const float *x, const float *alpha, float *dx
  * sum_r ((b[r][c]-mean[c])*invstd[c])^2; deterministic tree.
  * Bias gradients and the BatchNorm / LayerNorm parameter gradients. */
 size_t cer_col_sum_workspace_bytes(int R, int C);
+/* db = sum dy, dw = sum dy * (x - mean) * invstd over dense rows [R, C] -- the two reductions of the train-mode BatchNorm
+ * backward -- in ONE pass over dy and x when C % 4 == 0 and R spans several slabs (two passes otherwise); workspace as cer_col_sum */
+int cer_bn_bwd_sums(const float *dy, const float *x, const float *save_mean, const float *save_invstd, float *db, float *dw,
+                    int R, int C, void *workspace, size_t workspace_bytes, void *stream);
 int cer_col_sum(const float *a, int a_ld, const float *b, int b_ld, const float *mean, const float *invstd,
                 float *out, int R, int C, void *workspace, size_t workspace_bytes, void *stream);
 
