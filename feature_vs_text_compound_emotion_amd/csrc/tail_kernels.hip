@@ -720,16 +720,16 @@ __global__ void bn_rows_finish_kernel(const float *__restrict__ mean, float *__r
     }
 }
 
-// s1 = sum (x - k), s2 = sum (x - k)^2 with k = running_mean (before its update)  ->  mean, invstd, running buffers
+// s1 = sum (x - k), s2 = sum (x - k)^2 with the shift row k  ->  mean, invstd, running buffers
 __global__ void bn_rows_shifted_finish_kernel(float *__restrict__ s1_to_mean, float *__restrict__ s2_to_invstd,
-                                              float *__restrict__ running_mean, float *__restrict__ running_var, int R, int C,
-                                              float eps, float momentum) {
+                                              const float *__restrict__ shift, float *__restrict__ running_mean,
+                                              float *__restrict__ running_var, int R, int C, float eps, float momentum) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
     const double d1 = (double)s1_to_mean[c] / R, d2 = (double)s2_to_invstd[c] / R;
     double var = d2 - d1 * d1;
     var = var > 0.0 ? var : 0.0;
-    const float mean = (float)((double)running_mean[c] + d1);
+    const float mean = (float)((double)shift[c] + d1);
     s1_to_mean[c] = mean;
     s2_to_invstd[c] = rsqrtf((float)var + eps);
     running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
@@ -749,10 +749,11 @@ extern "C" int cer_bn_rows_fwd(const float *x, int x_ld, const float *w, const f
     if (train) {
         if (!save_mean || !save_invstd) return cer_set_error(CER_ERR_INVALID_ARG, "bn_rows_fwd: train needs save buffers");
         if (R > 2048 && x_ld == C &&
-            col_sum_pair(nullptr, x, running_mean, nullptr, save_mean, save_invstd, R, C, workspace, workspace_bytes, stream)) {
-            // ONE pass: sum (x - k) and sum (x - k)^2 about the shift k = the running mean (a per-channel constant known before
-            // the pass; any k is exact algebra, a k near the batch mean keeps E[d^2] - E[d]^2 free of cancellation)
-            CER_LAUNCH(bn_rows_shifted_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, save_mean, save_invstd, running_mean,
+            col_sum_pair(nullptr, x, x, nullptr, save_mean, save_invstd, R, C, workspace, workspace_bytes, stream)) {
+            // ONE pass: sum (x - k) and sum (x - k)^2 about the shift k[c] = x[0][c], the column's own first value (any k is
+            // exact algebra; a sample of the column lies within a few sigma of its mean, so E[d^2] - E[d]^2 does not cancel
+            // whatever the column's offset -- the running mean would do only once it has converged)
+            CER_LAUNCH(bn_rows_shifted_finish_kernel, dim3((C + 255) / 256), dim3(256), 0, ST, save_mean, save_invstd, x, running_mean,
                        running_var, R, C, eps, momentum);
         } else if (R > 2048) {
             int rc = cer_col_sum(x, x_ld, nullptr, 0, nullptr, nullptr, save_mean, R, C, workspace, workspace_bytes, stream);
