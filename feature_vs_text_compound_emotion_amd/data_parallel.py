@@ -70,6 +70,7 @@ class ClipDataParallel:
         # ``overlap="force"`` keeps the hook-driven slices on with ONE rank too (a single-rank RCCL communicator is legal):
         # the path the first multi-GPU run will take, exercised on one GPU (tests/test_rccl_single_rank_gpu.py)
         self.overlap = bool(overlap) and dist.is_initialized() and (self.world > 1 or overlap == "force")
+        self._gathered = True          # p.grad are bucket views right now
         self.buckets, self._works = [], []
         if self.overlap:
             self._build_buckets(bucket_mb)
@@ -154,21 +155,60 @@ class ClipDataParallel:
                 off += b.numel()
 
     def zero_grad(self):
-        """Keeps the views alive (``optimizer.zero_grad(set_to_none=True)`` would drop them)."""
+        """Overlapped exchange: the bucket is zeroed and every ``p.grad`` is (again) a view into it, so autograd accumulates in
+        place and the slice hooks see the gradients land.  Otherwise (round 3): ``p.grad = None`` -- autograd then ADOPTS the
+        gradient tensor a backward function returns instead of launching one ``grad += g`` kernel per parameter (102 launches
+        of ~2 us work each per step for the tri-modal LFAN tail), and ``gather_gradients()`` moves them into the bucket with a
+        few multi-tensor copies before the all-reduce / the fused optimiser reads it."""
+        if not self.overlap:
+            for p in self.params:
+                p.grad = None
+            self._gathered = False
+            return
         self.flat.zero_()
-        if self.overlap:
-            self._pending = [b[2] for b in self.buckets]
-            self._launched = [False] * len(self.buckets)
-            self._next = len(self.buckets) - 1
-            self._works = []
+        self._pending = [b[2] for b in self.buckets]
+        self._launched = [False] * len(self.buckets)
+        self._next = len(self.buckets) - 1
+        self._works = []
+        self._gathered = True
         off = 0
         for p in self.params:
             if p.grad is None or p.grad.data_ptr() != self.flat.data_ptr() + 4 * off:
                 p.grad = self.flat[off:off + p.numel()].view_as(p)
             off += p.numel()
 
+    def gather_gradients(self):
+        """Bring every parameter's gradient into the flat bucket (a no-op when they already live there) and make ``p.grad`` the
+        bucket views again; parameters that received no gradient read as zeros.  Idempotent per ``zero_grad()``."""
+        if getattr(self, "_gathered", True):
+            return
+        base = self.flat.data_ptr()
+        dsts, srcs, zeros, off = [], [], [], 0
+        views = []
+        for p in self.params:
+            v = self.flat[off:off + p.numel()].view_as(p)
+            views.append(v)
+            g = p.grad
+            if g is None:
+                zeros.append(v)
+            elif g.data_ptr() != base + 4 * off:
+                dsts.append(v)
+                srcs.append(g if g.dtype == torch.float32 else g.float())
+            off += p.numel()
+        if off < self.flat.numel():
+            zeros.append(self.flat[off:])
+        with torch.no_grad():
+            if dsts:
+                torch._foreach_copy_(dsts, srcs)
+            if zeros:
+                torch._foreach_zero_(zeros)
+        for p, v in zip(self.params, views):
+            p.grad = v
+        self._gathered = True
+
     def all_reduce_gradients(self):
         """Mean of the gradients over ranks, in place in the bucket."""
+        self.gather_gradients()
         if self.world > 1 or self.overlap:
             if self.overlap:
                 while self._next >= 0:   # slices at / below one whose parameters got no gradient this step, same order
@@ -218,6 +258,7 @@ class FlatNesterovSGD:
 
     def step(self):
         from . import ops
+        self.ddp.gather_gradients()
         g = self.param_groups[0]
         ops.sgd_nesterov_flat(self.flat_param, self.ddp.flat, self.buf, g["lr"], g["momentum"], g["dampening"],
                               g["weight_decay"], g["nesterov"], first_step=self.steps == 0)

@@ -33,8 +33,9 @@ def _worker(rank, world, port, out):
         ddp.zero_grad()
         loss = torch.nn.functional.cross_entropy(model(xs[idx]), ys[idx])
         loss.backward()
-        assert all(p.grad.data_ptr() >= ddp.flat.data_ptr() for p in ddp.params)  # still views of the bucket
         ddp.all_reduce_gradients()
+        lo, hi = ddp.flat.data_ptr(), ddp.flat.data_ptr() + 4 * ddp.flat.numel()
+        assert all(lo <= p.grad.data_ptr() < hi for p in ddp.params)  # views of the bucket (gathered there before the exchange)
         opt.step()
     out[rank] = {k: v.clone() for k, v in model.state_dict().items() if "running" not in k and "num_batches" not in k}
     dist.barrier()
@@ -57,9 +58,18 @@ def test_single_process_bucket_views_and_zero_grad():
     ddp = ClipDataParallel(model, world_size=1)
     model(torch.ones(3, 4)).sum().backward()
     assert ddp.flat.abs().sum() > 0
-    assert model.weight.grad.data_ptr() == ddp.flat.data_ptr()
+    assert model.weight.grad.data_ptr() == ddp.flat.data_ptr()       # first step: the views set up by the constructor
+    # zero_grad drops the gradients (autograd then adopts what backward returns: no per-parameter add kernels) ...
     ddp.zero_grad()
-    assert ddp.flat.abs().sum() == 0 and model.weight.grad.abs().sum() == 0
+    assert model.weight.grad is None and model.bias.grad is None
+    (model(torch.ones(3, 4))[:, 0] * 0 + model.weight.sum()).sum().backward()     # a step in which the bias gets NO gradient
+    assert model.weight.grad.data_ptr() != ddp.flat.data_ptr()
+    # ... and gather_gradients() brings them into the bucket (zeros for a parameter without gradient, stale values gone)
+    ddp.all_reduce_gradients()
+    assert model.weight.grad.data_ptr() == ddp.flat.data_ptr() and torch.equal(model.weight.grad, torch.full((2, 4), 3.0))
+    assert model.bias.grad.abs().sum() == 0 and ddp.flat[8:].abs().sum() == 0
+    ddp.gather_gradients()                                            # idempotent
+    assert torch.equal(model.weight.grad, torch.full((2, 4), 3.0))
 
 
 def _worker_overlap(rank, world, port, out):
