@@ -30,7 +30,7 @@ def test_flat_sgd_matches_torch_sgd(nesterov, wd, mu):
         for pr, pm in zip(ref.parameters(), mine.parameters()):
             grad = torch.randn(pr.shape, generator=g).cuda()
             pr.grad = grad.clone()
-            pm.grad.copy_(grad)  # views into the flat bucket
+            pm.grad = grad.clone()  # what autograd leaves after zero_grad(): the optimiser gathers it into the flat bucket
         opt_ref.step()
         opt.step()
         for pr, pm in zip(ref.parameters(), mine.parameters()):
