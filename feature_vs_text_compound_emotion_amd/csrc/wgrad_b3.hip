@@ -53,9 +53,13 @@ __device__ __forceinline__ int wg_off(int row, int ch) { return 256 * row + 16 *
 template <int TS, bool SPLIT_IN, bool DMA = false>
 __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) {
     static_assert(!DMA || (SPLIT_IN && TS == 128), "the DMA loader copies split planes into full 256-byte rows");
-    constexpr int KS = 32, PLANE = KS * 256, STAGE = 4 * PLANE;       // planes per stage: dZ hi, dZ lo, X hi, X lo
+    // KG pixel groups of 32 per stage: the 64-wide tile fills only half of a 256-byte LDS row, so a second group of 32 pixels
+    // lives in the other eight 16-byte slots of the same rows (chunk + 8; the XOR swizzle is a bijection on the 16 slots of a
+    // row) -- 64 pixels and twice the MFMAs per barrier in the same 32 KiB stage (round 3: the 64-channel layers ran at 0.11)
+    constexpr int KG = TS == 64 ? 2 : 1;
+    constexpr int KS = 32 * KG, PLANE = 32 * 256, STAGE = 4 * PLANE;  // planes per stage: dZ hi, dZ lo, X hi, X lo
     constexpr int NTW = TS / 32;                                      // 16-wide MFMA tiles per wave and side
-    constexpr int LPT = TS / 32;                                      // float4 loads per thread, operand and step
+    constexpr int LPT = TS / 32 * KG;                                 // float4 loads per thread, operand and step
     __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: the DMA destinations are scalar
@@ -135,8 +139,8 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
         unsigned char *base = smem + buf * STAGE;
 #pragma unroll
         for (int i = 0; i < LPT; ++i) {
-            const int row = lrow + RSTEP * i;
-            const int byte = wg_off(row, col4 >> 3) + 8 * ((col4 >> 2) & 1);
+            const int prow_ = lrow + RSTEP * i, row = prow_ & 31;      // pixel row of the step -> LDS row, slot group prow_ >> 5
+            const int byte = wg_off(row, (col4 >> 3) + 8 * (prow_ >> 5)) + 8 * ((col4 >> 2) & 1);
             if constexpr (SPLIT_IN) {
                 *reinterpret_cast<float2 *>(base + byte) = make_float2(ra[i].x, ra[i].y);
                 *reinterpret_cast<float2 *>(base + PLANE + byte) = make_float2(ra[i].z, ra[i].w);
@@ -158,15 +162,17 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
     // ---- transposed operand reads: lane 4q + p of a 16-lane group supplies row r0 + q, columns 4p .. 4p+3 of the block;
     // group kg reads rows 8 kg .. 8 kg + 3 and 8 kg + 4 .. 8 kg + 7 (the 8 pixels of its k group) ----
     const int q4 = l15 >> 2, p4 = l15 & 3;
-    int tr_a[NTW][2], tr_b[NTW][2];   // byte offsets inside a plane: [16-channel tile of this wave][row half]
+    int tr_a[KG][NTW][2], tr_b[KG][NTW][2];   // byte offsets inside a plane: [pixel group][16-channel tile of this wave][row half]
 #pragma unroll
-    for (int t = 0; t < NTW; ++t)
+    for (int g = 0; g < KG; ++g)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-            const int row = 8 * kg + 4 * h + q4;
-            tr_a[t][h] = wg_off(row, 2 * (wi * NTW + t) + (p4 >> 1)) + 8 * (p4 & 1);
-            tr_b[t][h] = wg_off(row, 2 * (wj * NTW + t) + (p4 >> 1)) + 8 * (p4 & 1);
-        }
+        for (int t = 0; t < NTW; ++t)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+                const int row = 8 * kg + 4 * h + q4;
+                tr_a[g][t][h] = wg_off(row, 8 * g + 2 * (wi * NTW + t) + (p4 >> 1)) + 8 * (p4 & 1);
+                tr_b[g][t][h] = wg_off(row, 8 * g + 2 * (wj * NTW + t) + (p4 >> 1)) + 8 * (p4 & 1);
+            }
     // (fragments travel as short vectors and are re-typed at the MFMA: a lambda returning a __bf16 vector made hipcc's host
     // pass drop the kernel stub, see conv_b3_patch.hip)
     auto frag = [&](const unsigned char *plane, const int off[2]) {
@@ -254,28 +260,31 @@ __global__ __launch_bounds__(256, 2) void conv2d_wgrad_b3_kernel(Wgrad2dArgs p) 
             if (s + 1 < steps) load_step(r_begin + (s + 1) * KS);
         }
         const unsigned char *base = smem + buf * STAGE;
-        s16x8 bh[NTW], bl[NTW];
 #pragma unroll
-        for (int t = 0; t < NTW; ++t) {
-            bh[t] = frag(base + 2 * PLANE, tr_b[t]);
-            bl[t] = frag(base + 3 * PLANE, tr_b[t]);
-        }
+        for (int g = 0; g < KG; ++g) {
+            s16x8 bh[NTW], bl[NTW];
 #pragma unroll
-        for (int a = 0; a < NTW; ++a) {
-            const s16x8 ah = frag(base, tr_a[a]), al = frag(base + PLANE, tr_a[a]);
+            for (int t = 0; t < NTW; ++t) {
+                bh[t] = frag(base + 2 * PLANE, tr_b[g][t]);
+                bl[t] = frag(base + 3 * PLANE, tr_b[g][t]);
+            }
 #pragma unroll
-            for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(al), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
+            for (int a = 0; a < NTW; ++a) {
+                const s16x8 ah = frag(base, tr_a[g][a]), al = frag(base + PLANE, tr_a[g][a]);
 #pragma unroll
-            for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah), as_bf16(bl[b]), acc[a][b], 0, 0, 0);
+                for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(al), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
 #pragma unroll
-            for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
-        }
-        // issue order (round 3): X fragments + the first dZ pair, then the reads of pair a + 1 in front of the MFMAs of pair a
-        __builtin_amdgcn_sched_group_barrier(0x100, 4 * NTW + 4, 0);
+                for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah), as_bf16(bl[b]), acc[a][b], 0, 0, 0);
 #pragma unroll
-        for (int a = 0; a < NTW; ++a) {
-            if (a + 1 < NTW) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 3 * NTW, 0);
+                for (int b = 0; b < NTW; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_bf16(ah), as_bf16(bh[b]), acc[a][b], 0, 0, 0);
+            }
+            // issue order (round 3): X fragments + the first dZ pair, then the reads of pair a + 1 in front of the MFMAs of pair a
+            __builtin_amdgcn_sched_group_barrier(0x100, 4 * NTW + 4, 0);
+#pragma unroll
+            for (int a = 0; a < NTW; ++a) {
+                if (a + 1 < NTW) __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 3 * NTW, 0);
+            }
         }
         if constexpr (DMA) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the next stage has landed
@@ -535,7 +544,7 @@ static int wgrad_b3_run(const float *dz, const float *x, const uint16_t *dz_hi, 
         return cer_set_error(CER_ERR_WORKSPACE, "conv2d_wgrad_b3: workspace too small");
     Wgrad2dArgs a{dz, x, dz_hi, dz_lo, x_hi, x_lo, splits > 1 ? (float *)workspace : dw, R, Cout, Cin, taps, KW, H, W, Ho, Wo,
                   stride, pad_t, pad_l, 0, tiles, splits};
-    a.rows_per_split = ((R + splits - 1) / splits + 31) / 32 * 32;
+    a.rows_per_split = ts == 64 ? ((R + splits - 1) / splits + 63) / 64 * 64 : ((R + splits - 1) / splits + 31) / 32 * 32;
     const dim3 grid((unsigned)((splits + 7) / 8 * 8 * tiles * taps));
     hipStream_t st = (hipStream_t)stream;
     if (ts == 256) {
