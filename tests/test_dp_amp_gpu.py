@@ -35,10 +35,18 @@ def _model(seed=0, conditioned=False):
     return model.cuda()
 
 
-def _steps(model, ddp, opt, x, labels, n_steps=2):
-    """eval-mode BatchNorm / no dropout, but a real backward: every clip's gradient is independent of its batch mates"""
+def _steps(model, ddp, opt, x, labels, n_steps=2, train=False):
+    """eval-mode BatchNorm / no dropout, but a real backward: every clip's gradient is independent of its batch mates.
+    ``train``: model.train() with dropout off -- batch-statistics BatchNorm, local to the rank."""
     from feature_vs_text_compound_emotion_amd.lfan import cross_entropy_loss
     model.eval()
+    if train:
+        model.train()
+        for mod in model.modules():
+            if isinstance(mod, torch.nn.Dropout):
+                mod.p = 0.0
+        for net in model.temporal.values():
+            net.dropout = 0.0
     grads = None
     for _ in range(n_steps):
         ddp.zero_grad()
@@ -52,7 +60,11 @@ def _steps(model, ddp, opt, x, labels, n_steps=2):
     return grads, ddp.flat_param.clone()
 
 
-def _worker(rank, world, port, out):
+def _worker_train(rank, world, port, out):
+    _worker(rank, world, port, out, train=True)
+
+
+def _worker(rank, world, port, out, train=False):
     os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       HSA_ENABLE_IPC_MODE_LEGACY="0")
     import sys
@@ -70,7 +82,7 @@ def _worker(rank, world, port, out):
     x, labels = synth.make_clip_batch(MODS, B, L, hw=HW, seed=55)
     idx = ddp.shard(list(range(B)), rank)
     xs = {k: v[idx].cuda() for k, v in x.items()}
-    g, w = _steps(model, ddp, opt, xs, labels[idx].cuda())
+    g, w = _steps(model, ddp, opt, xs, labels[idx].cuda(), n_steps=1 if train else 2, train=train)
     out[rank] = (g.cpu(), w.cpu())
     dist.barrier()
     dist.destroy_process_group()
@@ -96,6 +108,35 @@ def test_two_ranks_on_half_batches_equal_one_rank_on_the_full_batch():
     print(f"\n[dp] 2 ranks x {B // 2} clips vs 1 rank x {B} clips: relative gradient difference {gerr:.2e}, weight difference {werr:.2e}")
     assert gerr < 2e-5          # mean of two half-batch means vs one full-batch mean: fp32 summation order only
     assert werr < 1e-7
+
+
+def test_train_mode_ranks_apply_the_mean_of_their_shards_gradients():
+    """model.train() (batch-statistics BatchNorm in the encoder and the tail): the statistics are local to a rank -- each rank
+    IS the single-process reference run on its shard (torch DDP without SyncBN) -- and the applied gradient is the mean over
+    ranks.  So the all-reduced gradient of 2 ranks has to equal the mean of two single-process gradients, one per shard
+    (NOT the gradient of one process on the full batch, whose BatchNorms would see other statistics)."""
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.data_parallel import ClipDataParallel, FlatNesterovSGD
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        mp.spawn(_worker_train, args=(world, port, out), nprocs=world, join=True)
+        (g0, w0), (g1, w1) = out[0], out[1]
+    assert torch.equal(g0, g1) and torch.equal(w0, w1)
+    x, labels = synth.make_clip_batch(MODS, B, L, hw=HW, seed=55)
+    singles = []
+    for r in range(world):
+        model = _model(seed=0)
+        ddp = ClipDataParallel(model, world_size=1)
+        opt = FlatNesterovSGD(ddp, lr=1e-3)
+        idx = list(range(B))[r::world]
+        g, _ = _steps(model, ddp, opt, {k: v[idx].cuda() for k, v in x.items()}, labels[idx].cuda(), n_steps=1, train=True)
+        singles.append(g.cpu())
+    mean = (singles[0] + singles[1]) / 2
+    err = (mean - g0).abs().max().item() / mean.abs().max().item()
+    print(f"\n[dp train] all-reduced gradient vs the mean of the two single-shard gradients: {err:.2e}")
+    assert err < 1e-6
 
 
 def test_sync_buffers_and_broadcast_move_version_counters():
