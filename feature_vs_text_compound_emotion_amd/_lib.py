@@ -74,6 +74,7 @@ _SIGNATURES = {
     "cer_prelu_split": (c_int, [_P, _P, _P, _P, c_size_t, c_int, _P]),
     "cer_prelu_bwd_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, c_int, _P]),
     "cer_bn_rows_bwd_split": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
+    "cer_bn_rows_bwd_add": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
     "cer_col_sum_workspace_bytes": (c_size_t, [c_int, c_int]),
     "cer_col_sum": (c_int, [_P, c_int, _P, c_int, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),
     "cer_bn_bwd_sums": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P, c_size_t, _P]),

@@ -419,6 +419,31 @@ __global__ void bn_rows_bwd_split_kernel(const float4 *__restrict__ dy, const fl
     lo[i] = l;
 }
 
+// the same apply pass with an fp32 result and an optional addend: dx = BatchNorm-backward(dy) + add -- the unit input's gradient
+// is the sum of the residual branch (through BatchNorm 1) and the shortcut branch (dout itself, or the projection's data
+// gradient), which used to be a separate read-modify-write pass over dx
+__global__ void bn_rows_bwd_add_kernel(const float4 *__restrict__ dy, const float4 *__restrict__ x, const float *__restrict__ mean,
+                                       const float *__restrict__ invstd, const float *__restrict__ w, const float *__restrict__ sum_dy,
+                                       const float *__restrict__ sum_dy_xhat, const float4 *__restrict__ add, float4 *__restrict__ dx,
+                                       size_t n4, int C4, float inv_r) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n4) return;
+    const int c = (int)(i % C4) * 4;
+    const float4 g = dy[i], v = x[i];
+    const float4 mu = *reinterpret_cast<const float4 *>(mean + c), is = *reinterpret_cast<const float4 *>(invstd + c);
+    const float4 ww = *reinterpret_cast<const float4 *>(w + c), s1 = *reinterpret_cast<const float4 *>(sum_dy + c);
+    const float4 s2 = *reinterpret_cast<const float4 *>(sum_dy_xhat + c);
+    float4 d = make_float4(ww.x * is.x * (g.x - (s1.x + (v.x - mu.x) * is.x * s2.x) * inv_r),
+                           ww.y * is.y * (g.y - (s1.y + (v.y - mu.y) * is.y * s2.y) * inv_r),
+                           ww.z * is.z * (g.z - (s1.z + (v.z - mu.z) * is.z * s2.z) * inv_r),
+                           ww.w * is.w * (g.w - (s1.w + (v.w - mu.w) * is.w * s2.w) * inv_r));
+    if (add) {
+        const float4 a = add[i];
+        d = make_float4(d.x + a.x, d.y + a.y, d.z + a.z, d.w + a.w);
+    }
+    dx[i] = d;
+}
+
 template <int BM, int BN, int WP, int WC, int NW = 4, int STAGES = 2>
 static int launch_b3_dma16(const ConvArgs &a, hipStream_t st) {
     if ((long long)BN * a.Kpad * 2 >= (1ll << 31))
@@ -551,6 +576,21 @@ extern "C" int cer_bn_rows_bwd_split(const float *dy, const float *x, const floa
     const size_t n4 = (size_t)R * (C / 4);
     CER_LAUNCH(bn_rows_bwd_split_kernel, dim3(cer_blocks(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)dy,
                (const float4 *)x, save_mean, save_invstd, w, (const float *)db, (const float *)dw, (ushort4 *)dx_hi, (ushort4 *)dx_lo, n4,
+               C / 4, 1.0f / (float)R);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+extern "C" int cer_bn_rows_bwd_add(const float *dy, const float *x, const float *save_mean, const float *save_invstd, const float *w,
+                                   const float *add, float *dx, float *dw, float *db, int R, int C, void *workspace,
+                                   size_t workspace_bytes, void *stream) {
+    if (!dy || !x || !save_mean || !save_invstd || !w || !dx || !dw || !db || R <= 0 || C <= 0 || (C & 3))
+        return cer_set_error(CER_ERR_INVALID_ARG, "bn_rows_bwd_add: bad argument (dense rows, C % 4 == 0)");
+    const int rc = cer_bn_bwd_sums(dy, x, save_mean, save_invstd, db, dw, R, C, workspace, workspace_bytes, stream);
+    if (rc) return rc;
+    const size_t n4 = (size_t)R * (C / 4);
+    CER_LAUNCH(bn_rows_bwd_add_kernel, dim3(cer_blocks(n4, 256)), dim3(256), 0, (hipStream_t)stream, (const float4 *)dy,
+               (const float4 *)x, save_mean, save_invstd, w, (const float *)db, (const float *)dw, (const float4 *)add, (float4 *)dx, n4,
                C / 4, 1.0f / (float)R);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;

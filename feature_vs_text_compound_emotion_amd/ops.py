@@ -898,8 +898,20 @@ def bn_rows_stats(x, running_mean, running_var, eps=1e-5, momentum=0.1):
     return sm, si
 
 
-def bn_rows_bwd(dy, x, save_mean, save_invstd, w, train=True, split_out=False):
-    """``split_out`` (train mode, dense rows): dx as a Split tensor written by the apply pass itself."""
+def bn_rows_bwd(dy, x, save_mean, save_invstd, w, train=True, split_out=False, add=None):
+    """``split_out`` (train mode, dense rows): dx as a Split tensor written by the apply pass itself.  ``add`` (train mode,
+    dense rows, C % 4 == 0): dx = BatchNorm-backward(dy) + add in the same pass."""
+    if add is not None:
+        for t, nme in ((dy, "dy"), (x, "x"), (add, "add")):
+            _dev_f32(t, nme)
+        r, c = dy.shape
+        if split_out or tuple(add.shape) != (r, c) or c % 4:
+            raise ValueError("bn_rows_bwd(add=...): fp32 result, add of the rows' shape, C % 4 == 0")
+        dx, dw, db = _empty((r, c), x), _empty((c,), x), _empty((c,), x)
+        ws, nbytes = _col_ws(r, c, x)
+        check(_lib.load().cer_bn_rows_bwd_add(ptr(dy), ptr(x), ptr(save_mean), ptr(save_invstd), ptr(w), ptr(add), ptr(dx), ptr(dw),
+                                              ptr(db), r, c, ptr(ws), nbytes, current_stream()), "cer_bn_rows_bwd_add")
+        return dx, dw, db
     if split_out:
         _dev_f32(dy, "dy")
         _dev_f32(x, "x")

@@ -262,32 +262,43 @@ class _ReleasedUnit(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[0]
         dxb = _conv_dgrad(dz1, w1, 1, 1, (h, w), dprec)
         del dz1
-        if xh is not None:   # x_hat is what was saved: mean 0, invstd 1, and the outer gamma * invstd factor as the "weight"
-            dx, dg1, db1 = ops.bn_rows_bwd(dxb.view(-1, cin), xh.view(-1, cin), torch.zeros_like(sm1), torch.ones_like(si1),
-                                           (g1 * si1).contiguous())
-            del xh
-        else:
-            dx, dg1, db1 = ops.bn_rows_bwd(dxb.view(-1, cin), x.view(-1, cin), sm1, si1, g1)
-        del dxb
-        dx = dx.view(n, h, w, cin)
+        # the shortcut branch's share of the input gradient: dout itself (identity), or the projection's data gradient; it is
+        # added inside the BatchNorm-1 backward pass (``add``) instead of a read-modify-write pass over dx afterwards
         dws = dgs = dbs = None
+        addend = even = None
         if ws is not None:
             dzs, dgs, dbs = ops.bn_rows_bwd(dout.view(-1, depth), zs.view(-1, depth), sms, sis, gs)
             dzs = dzs.view(n, ho, wo, depth)
             if split and s == 1:
                 dzs = ops.split_bf16(dzs)
             dws = ops.conv2d_wgrad(dzs, x, 1, 1, stride=s, pad=(0, 0), b3=b3)
+            even = None
             if need_dx:
                 if s == 1:
-                    ops.add_inplace(dx, _conv_dgrad(dzs, ws, 1, 0, (h, w), dprec))
-                else:   # a 1x1 / stride-2 conv only reaches the even input pixels
+                    addend = _conv_dgrad(dzs, ws, 1, 0, (h, w), dprec)
+                else:   # a 1x1 / stride-2 conv only reaches the even input pixels: a quarter-size result, added strided below
                     wt = ops.pack_conv_weight(ws.contiguous(), flip=False, transpose=True)
-                    dx[:, ::2, ::2] += _conv_prec(dzs, wt, 1, 1, 1, (0, 0), dprec)
-        elif need_dx:
-            if s > 1:
+                    even = _conv_prec(dzs, wt, 1, 1, 1, (0, 0), dprec)
+            del dzs
+        elif need_dx and s == 1:
+            addend = dout
+        rows_ok = need_dx and addend is not None and cin % 4 == 0
+        if xh is not None:   # x_hat is what was saved: mean 0, invstd 1, and the outer gamma * invstd factor as the "weight"
+            dx, dg1, db1 = ops.bn_rows_bwd(dxb.view(-1, cin), xh.view(-1, cin), torch.zeros_like(sm1), torch.ones_like(si1),
+                                           (g1 * si1).contiguous(), add=addend.view(-1, cin) if rows_ok else None)
+            del xh
+        else:
+            dx, dg1, db1 = ops.bn_rows_bwd(dxb.view(-1, cin), x.view(-1, cin), sm1, si1, g1,
+                                           add=addend.view(-1, cin) if rows_ok else None)
+        del dxb
+        dx = dx.view(n, h, w, cin)
+        if need_dx and not rows_ok:
+            if addend is not None:
+                ops.add_inplace(dx, addend)
+            elif ws is not None and s > 1:
+                dx[:, ::2, ::2] += even
+            elif ws is None and s > 1:
                 dx[:, ::s, ::s] += dout
-            else:
-                ops.add_inplace(dx, dout)
         return (dx if need_dx else None), None, None, None, dg1, db1, dw1, da1, dw2, dg2, db2, dws, dgs, dbs
 
 

@@ -171,6 +171,12 @@ int cer_prelu_bwd_split(const float *dy, const float *x, const float *alpha, flo
 int cer_bn_rows_bwd_split(const float *dy, const float *x, const float *save_mean, const float *save_invstd, const float *w,
                           uint16_t *dx_hi, uint16_t *dx_lo, float *dw, float *db, int R, int C, void *workspace,
                           size_t workspace_bytes, void *stream);
+/* cer_bn_rows_bwd (train mode, dense rows, C % 4 == 0) with an addend: dx = BatchNorm-backward(dy) + add (add may be NULL; it may
+ * alias dx).  The gradient of a unit's input is the sum of its residual branch (through the unit's first BatchNorm) and its
+ * shortcut branch (models/arcface_model.py:58-60): one pass instead of a BatchNorm-backward pass and an add pass. */
+int cer_bn_rows_bwd_add(const float *dy, const float *x, const float *save_mean, const float *save_invstd, const float *w,
+                        const float *add, float *dx, float *dw, float *db, int R, int C, void *workspace, size_t workspace_bytes,
+                        void *stream);
 
 /* v' = v*scale[c]+shift[c] (channels-last, C channels; scale/shift may be NULL) -> (bf16(v'), bf16(v' - bf16(v'))),
  * round-to-nearest-even on both parts. */
