@@ -37,10 +37,6 @@ struct ConvArgs {
     // cer_conv_desc.y_s2d: the 16-bit output planes are written space-to-depth (row permutation s2d_row() of the stores);
     // x_s2d: the input is such a tensor (x_ld = 4 Cin), conv_b3_s2d.hip
     int y_s2d, x_s2d;
-    // start stagger (two-blocks-per-CU kernels of the K-short layers): blocks of the first residency round that sit in an odd
-    // wave slot sleep `stagger` x 127 x 64 cycles before their first DMA, so that the two blocks of a CU alternate their
-    // memory and matrix phases instead of running them in lockstep (0 = off)
-    int stagger;
 };
 
 // Row of output pixel m = (n, ho, wo) in the space-to-depth view [N * Ho/2 * Wo/2 * 4][C] of an [N, Ho, Wo, C] tensor:

@@ -22,14 +22,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include <stdlib.h>
-
 #include "cer_internal.h"
 #include "conv_common.h"
-
-#ifndef CER_STAGGER_DEFAULT
-#define CER_STAGGER_DEFAULT 0
-#endif
 
 namespace cer {
 
@@ -534,10 +528,6 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
                                                       "output, residual, mask, aux or y_ld)");
     }
     a.x_s2d = d->x_s2d != 0; a.y_s2d = d->y_s2d != 0;
-    {   // tuning knob (tools/bench_conv.py): CER_STAGGER = units of the start stagger of the two-blocks-per-CU patch kernels
-        static const int stagger_env = [] { const char *e = getenv("CER_STAGGER"); return e ? atoi(e) : CER_STAGGER_DEFAULT; }();
-        a.stagger = stagger_env;
-    }
     a.x_ld = d->x_s2d ? 4 * d->Cin : (d->x_ld > 0 ? d->x_ld : d->Cin);
     a.y_ld = d->y_ld > 0 ? d->y_ld : d->Cout;
     if (a.x_ld < d->Cin || a.y_ld < d->Cout || ((d->Cin % 32) == 0 && (a.x_ld & 3) != 0))

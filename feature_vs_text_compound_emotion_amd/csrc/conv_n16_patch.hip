@@ -51,14 +51,6 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wp = wave % WP, wc = wave / WP;
     const int kg = lane >> 4, l15 = lane & 15;
-    if constexpr (XBUFS == 1 && !PP) {
-        if (p.stagger > 0 && blockIdx.x < 512) {
-            // HW_ID.WAVE_ID (hwreg 4, bits 3:0): the wave's slot on its SIMD -- the first block of a CU holds slot 0, the second slot 1
-            const unsigned slot_id = __builtin_amdgcn_s_getreg(4 | (0 << 6) | (3 << 11));
-            if (slot_id & 1)
-                for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-        }
-    }
 
     const int nwg = p.tiles_m * p.tiles_n;
     int bid = blockIdx.x;
