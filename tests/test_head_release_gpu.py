@@ -9,6 +9,8 @@ from helpers import golden
 
 pytestmark = pytest.mark.gpu
 
+_ORACLE_CACHE = {}
+
 
 def _setup():
     from feature_vs_text_compound_emotion_amd import synth
@@ -245,14 +247,23 @@ def test_whole_encoder_backward_vs_float64_oracle(precision, with_stem, n, hw, m
     frames = torch.randn(n, 3, hw, hw, generator=gen)
     G = torch.randn(n, 512, generator=gen)
     keep = (torch.rand(n, 512, hw // 8, hw // 8, generator=gen) >= 0.4).double() / 0.6
-    # float64 reference
-    sd64 = {k[len("backbone."):]: v.double().clone() for k, v in vsd.items() if k.startswith("backbone.")}
-    train_keys = [k for k in sd64 if not k.endswith(("running_mean", "running_var", "num_batches_tracked")) and
-                  (with_stem or not k.startswith("input_layer."))]
-    for k in train_keys:
-        sd64[k].requires_grad_(True)
-    emb64 = oracle_ir50.ir50_forward(frames.double(), sd64, train=True, head_dropout_mask=keep)
-    (emb64 * G.double()).sum().backward()
+    # float64 reference and the float32 yardstick (CPU autograd through the oracle: seconds each) are shared by the
+    # parametrisations that differ only in the HIP side (precision, memory plan)
+    key = (with_stem, n, hw)
+    if key not in _ORACLE_CACHE:
+        sd64 = {k[len("backbone."):]: v.double().clone() for k, v in vsd.items() if k.startswith("backbone.")}
+        train_keys = [k for k in sd64 if not k.endswith(("running_mean", "running_var", "num_batches_tracked")) and
+                      (with_stem or not k.startswith("input_layer."))]
+        for k in train_keys:
+            sd64[k].requires_grad_(True)
+        emb64 = oracle_ir50.ir50_forward(frames.double(), sd64, train=True, head_dropout_mask=keep)
+        (emb64 * G.double()).sum().backward()
+        sd32 = {k: v.detach().float().clone() for k, v in sd64.items()}
+        for k in train_keys:
+            sd32[k].requires_grad_(True)
+        (oracle_ir50.ir50_forward(frames, sd32, train=True, head_dropout_mask=keep.float()) * G).sum().backward()
+        _ORACLE_CACHE[key] = (sd64, train_keys, emb64.detach(), sd32)
+    sd64, train_keys, emb64, sd32 = _ORACLE_CACHE[key]
     # HIP
     vb = VisualBackbone(use_pretrained=False, head_hw=hw // 8)
     vb.load_state_dict(vsd, strict=True)
@@ -273,12 +284,8 @@ def test_whole_encoder_backward_vs_float64_oracle(precision, with_stem, n, hw, m
     (emb * G.cuda()).sum().backward()
     if not with_stem:
         assert all(named[k].grad is None for k in named if k.startswith("input_layer."))
-    # yardstick: torch's own float32 autograd through the same oracle -- how far plain fp32 arithmetic lands from float64 on
-    # this 24-unit, batch-statistics, 8-frame problem
-    sd32 = {k: v.detach().float().clone() for k, v in sd64.items()}
-    for k in train_keys:
-        sd32[k].requires_grad_(True)
-    (oracle_ir50.ir50_forward(frames, sd32, train=True, head_dropout_mask=keep.float()) * G).sum().backward()
+    # yardstick (sd32, cached above): torch's own float32 autograd through the same oracle -- how far plain fp32 arithmetic
+    # lands from float64 on this 24-unit, batch-statistics, 8-frame problem
 
     def errors(grad_of):
         num = den = 0.0

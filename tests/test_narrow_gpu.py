@@ -66,7 +66,7 @@ def test_narrow_embedding_vs_oracle(n, hw, precision):
         emb = _vb(vsd, hw // 8, precision)(frames.cuda()).cpu()
         rel, cos = _emb_errors(emb, ref)
         msg = f"\n[narrow {precision}] IR-50 eval n={n} hw={hw}: relative L2 {rel:.2e}, min cosine {cos:.6f}"
-        if hw <= 64:      # the autocast oracle at 224x224 costs minutes of CPU bf16 convs; the small shapes carry the yardstick
+        if n * hw * hw <= 8 * 40 * 40:      # the autocast oracle is CPU bf16 / fp16 conv work: the small shapes carry the yardstick
             yard, _ = _emb_errors(autocast_ir50_forward(frames, vsd, "backbone.", DT[precision]), ref)
             msg += f"; reference autocast arithmetic {yard:.2e}"
             assert rel < YARDSTICK_EMB * yard
@@ -138,7 +138,9 @@ def test_cfg5_trimodal_64_frame_clips_8_classes(precision):
     with torch.no_grad():
         logits = model(dict(xd)).cpu()
         ref = lfan_forward(x, sd, MODS, train=False)
-        yard = (autocast_lfan_forward(x, sd, MODS, DT[precision], train=False) - ref).abs().max().item()
+        # (fp16 autocast on the CPU costs ~25 s per 128-frame forward: its eval-mode yardstick is taken on the first clip only)
+        xy = x if precision == "bf16" else {k: v[:1] for k, v in x.items()}
+        yard = (autocast_lfan_forward(xy, sd, MODS, DT[precision], train=False) - ref[:xy["video"].shape[0]]).abs().max().item()
     assert logits.shape == (b, length, n_cls)
     err = (logits - ref).abs().max().item()
     agree = (logits.argmax(-1) == ref.argmax(-1)).float().mean().item()
