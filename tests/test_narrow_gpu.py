@@ -130,7 +130,7 @@ def test_cfg5_trimodal_64_frame_clips_8_classes(precision):
     from oracle.lfan import cross_entropy_mean, lfan_forward
     import oracle.lfan as oracle_lfan
     from oracle.narrow import autocast_lfan_forward, ir50_forward_narrow_storage
-    b, length, hw, n_cls = 2, 64, 40, 8
+    b, length, hw, n_cls = (2 if precision == "bf16" else 1), 64, 40, 8     # (fp16 autocast on the CPU is slow: one 64-frame clip)
     sd = synth.lfan_state_dict(MODS, n_cls=n_cls, head_hw=hw // 8, seed=0)
     x, labels = synth.make_clip_batch(MODS, b, length, hw=hw, seed=4321, n_cls=n_cls)
     model = _lfan(sd, n_cls, length, hw, precision).eval()
