@@ -444,7 +444,8 @@ class Workload:
                        "model": cfg["model"], "modalities": mods, "encoders_on_gpu": cfg["encoders"] == "on",
                        "clips_per_gpu": cfg["batch"], "global_batch": cfg["batch"] * self.world, "frames_per_clip": cfg["length"],
                        "frame_hw": cfg["hw"], "n_classes": cfg["n_cls"], "released_encoder_groups": cfg["release"],
-                       "released_units_activation_memory": cfg["act_mem"] if cfg["release"] else None,
+                       "released_units_activation_memory": (getattr(self.model.spatial["visual"].backbone, "_act_mem", cfg["act_mem"])
+                                                            if cfg["release"] else None),
                        "trainable_parameters": int(sum(p.numel() for p in self.ddp.params)), "conv_precision": cfg["precision"],
                        "parallelism": f"dp{self.world} over clips, flat-bucket RCCL all-reduce", "loss": float(loss.item())},
             "roofline": roofline}
@@ -496,7 +497,7 @@ def main():
     ap.add_argument("--act-mem", choices=["auto", "raw", "recompute", "recompute16"], default="auto",
                     help="released encoder units: raw = keep the raw conv results for the backward (410 MB per 224x224 frame); "
                          "recompute = keep unit inputs as one fp16 plane (62 MB per frame) and re-run the unit's convs in the "
-                         "backward; auto = recompute when the raw tensors of the batch would not fit (> 384 frames of 224x224)")
+                         "backward (bit-identical gradients); auto = raw when it fits the free device memory, else recompute")
     ap.add_argument("--encoders", choices=["on", "off"], default="on",
                     help="on: VGGish (log-mel from PCM) and BERT (64 tokens) run on the GPU inside the step; "
                          "off: pre-computed per-frame features, as the reference trainer feeds them")
@@ -519,8 +520,7 @@ def main():
     mods = a.modalities.split(",") if a.modalities else (ALL_MODS if a.model == "LFAN" else ["video", "vggish"])
     cfg = {"model": a.model, "modalities": mods, "hw": a.hw, "batch": a.batch, "length": a.length, "n_cls": a.n_cls,
            "precision": a.precision, "release": a.release, "encoders": a.encoders}
-    raw_bytes = 410e6 * (a.hw / 224.0) ** 2 * a.batch * a.length    # raw tensors of all 24 units + the stem, fp32
-    cfg["act_mem"] = a.act_mem if a.act_mem != "auto" else ("recompute" if a.release == 4 and raw_bytes > 160e9 else "raw")
+    cfg["act_mem"] = a.act_mem      # "auto": the encoder picks raw / recompute from the free device memory (IR50.activation_memory)
     wl = Workload(cfg, rank, world, dev)
     res = wl.measure(a.steps, a.warmup)
     wl.close()

@@ -414,9 +414,11 @@ class IR50(nn.Module):
         self._packed_train_n16_key = None
         self.dropout_seed = 0
         self._dropout_calls = 0
-        # released units: "raw" keeps the raw conv results for the backward (fp32), "recompute" keeps the unit inputs as one
-        # fp16 plane and re-runs the unit's convs in the backward (_ReleasedUnit)
-        self.activation_memory = "raw"
+        # released units (_ReleasedUnit): "raw" keeps the raw conv results for the backward, "recompute" only the unit inputs
+        # (the unit's convs run again in the backward; gradients bit-identical to "raw"), "recompute16" the normalised
+        # inputs as one fp16 plane (lossy); "auto" = "raw" when its ~410 MB per 224x224 frame fit the free device memory
+        # with room for the backward's transients, else "recompute"
+        self.activation_memory = "auto"
 
     def __deepcopy__(self, memo):
         """trainer.py:656,705 deep-copies the model: copy parameters/buffers, not the packed caches."""
@@ -673,6 +675,8 @@ class IR50(nn.Module):
         n = x.shape[0]
         plan = self._release_plan()
         first_released = len(P["units"]) if plan is None else plan
+        if plan is not None:
+            self._resolve_activation_memory(x.shape[0], x.shape[2])
         y = ys = xst = None
         if plan is not None and self._stem_released():
             y = self._released_stem(x)
@@ -789,6 +793,8 @@ class IR50(nn.Module):
         n = x.shape[0]
         plan = self._release_plan()
         first_released = len(P["units"]) if plan is None else plan
+        if plan is not None:
+            self._resolve_activation_memory(x.shape[0], x.shape[2])
         y = ys = xst = None
         if plan is not None and self._stem_released():
             y = self._released_stem(x)
@@ -887,12 +893,24 @@ class IR50(nn.Module):
         il = self.input_layer
         return _ReleasedStem.apply(x, il[1], il[0].weight, il[1].weight, il[1].bias, il[2].weight)
 
+    def _resolve_activation_memory(self, frames, hw):
+        """What the released units of THIS forward keep (see ``activation_memory``); called once per forward."""
+        mode = self.activation_memory
+        if mode not in ("auto", "raw", "recompute", "recompute16"):
+            raise ValueError(f"unknown activation_memory {mode!r}")
+        if mode == "auto":
+            released = sum(1 for u in self.body if all(p.requires_grad for p in u.parameters()))
+            raw = 410e6 * (hw / 224.0) ** 2 * frames * released / len(self.body)      # fp32 raw tensors of the released units
+            free, _ = torch.cuda.mem_get_info()
+            free += torch.cuda.memory_reserved() - torch.cuda.memory_allocated()      # the allocator's cached blocks are reusable
+            mode = "raw" if 1.6 * raw < free else "recompute"
+        self._act_mem = mode
+        return mode
+
     def _released_unit(self, u, y, prec="fp32"):
-        if self.activation_memory not in ("raw", "recompute", "recompute16"):
-            raise ValueError(f"unknown activation_memory {self.activation_memory!r}")
         pr = u.res_layer
         sc = u.shortcut_layer if u.cin != u.depth else None
-        return _ReleasedUnit.apply(y, u, prec, self.activation_memory, pr[0].weight, pr[0].bias, pr[1].weight, pr[2].weight, pr[3].weight, pr[4].weight,
+        return _ReleasedUnit.apply(y, u, prec, self._act_mem, pr[0].weight, pr[0].bias, pr[1].weight, pr[2].weight, pr[3].weight, pr[4].weight,
                                    pr[4].bias, sc[0].weight if sc is not None else None,
                                    sc[1].weight if sc is not None else None, sc[1].bias if sc is not None else None)
 
@@ -921,6 +939,8 @@ class IR50(nn.Module):
         n = x.shape[0]
         plan = self._release_plan()
         first_released = len(P["units"]) if plan is None else plan
+        if plan is not None:
+            self._resolve_activation_memory(x.shape[0], x.shape[2])
         xst = None
         if plan is not None and self._stem_released():
             y = self._released_stem(x)
