@@ -144,3 +144,58 @@ def test_gradual_release_groups_are_head_then_stage4_then_half_of_stage3():
     assert t.calls == 3 and t.early_stopping_counter == 7 and pc.release_count == 0
     pc.release_param(spatial)
     assert pc.early_stop
+
+
+def test_trainer_accepts_the_reference_keyword_surface_and_runs_optimize():
+    """experiment.py:153-214: Trainer(**trainer_kwards); set_args; post_set_args; set_number_classes;
+    init_optimizer_and_scheduler(epoch=0); optimize(dataloaders, ...) -- with a stub model on the CPU (host aggregation)."""
+    from types import SimpleNamespace
+
+    class M(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(128, 7)
+
+        def forward(self, X):
+            return self.lin(X["vggish"][:, 0])
+
+    crit = torch.nn.CrossEntropyLoss(reduction="mean")
+    kwargs = {"device": "cpu", "emotion": "expr", "model_name": "LFAN", "models": M(), "save_path": "/tmp/x", "fold": 0,
+              "min_epoch": 0, "max_epoch": 3, "early_stopping": 50, "learning_rate": 1e-3, "min_learning_rate": 1e-6,
+              "patience": 5, "train_batch_size": 2, "eval_batch_size": 1, "criterion": crit, "factor": 0.1, "verbose": True,
+              "milestone": [0], "metrics": ["f1"], "load_best_at_each_epoch": False, "save_plot": False}
+    tr = Trainer(**kwargs)
+    assert tr.max_epoch == 3 and tr.train_batch_size == 2 and tr.early_stopping == 50
+    args = SimpleNamespace(window_length=6, hop_length=4, model_name="LFAN", amp=False, seed=0,
+                           opt__name_optimizer="sgd", opt__lr=1e-3, opt__momentum=0.9, opt__dampening=0.0,
+                           opt__weight_decay=1e-4, opt__nesterov=True, opt__lr_scheduler=True, opt__name_lr_scheduler="mystep",
+                           opt__step_size=2, opt__gamma=0.5)
+    tr.set_args(args)
+    tr.post_set_args({"Neutral": 0, "Anger": 1})
+    assert tr.int_to_cl == {0: "Neutral", 1: "Anger"}
+    tr.set_number_classes(7)
+    tr.init_optimizer_and_scheduler(epoch=0)
+    assert isinstance(tr.optimizer, torch.optim.SGD) and tr.optimizer.defaults["nesterov"] and tr.scheduler is not None
+    assert tr.optimizer.defaults["lr"] == 1e-3           # instantiators.py builds SGD WITHOUT lr: torch's default
+    g = torch.Generator().manual_seed(0)
+    w_true = torch.randn(128, 7, generator=g)
+
+    def clips(n_clips, length, batch):
+        out = []
+        for i in range(0, n_clips, batch):
+            x = torch.randn(batch, 1, length, 128, generator=g)
+            y = (x[:, 0].mean(1) @ w_true).argmax(-1).view(batch, 1, 1).expand(batch, length, 1).float().contiguous()   # one label per video (metrics.py:104-105)
+            out.append(({"vggish": x, "EXPR_continuous_label": y}, [f"c{i + j}" for j in range(batch)], [length] * batch,
+                        [np.arange(length)] * batch))
+        return out
+    loaders = {"train": clips(8, 6, 2), "valid": clips(3, 9, 1), "test": clips(2, 13, 1)}   # 9 / 13 frames: windowed inference
+    hist = tr.optimize(loaders, checkpoint_controller=None, parameter_controller=None)
+    assert tr.fit_finished and len(hist["loss"]) == 3 and len(hist["valid"]) == 4
+    assert hist["loss"][-1] < hist["loss"][0]
+    assert set(hist["test_logits"]) == {"c0", "c1"} and hist["test_logits"]["c0"]["logits"].shape == (13, 7)
+    assert 0.0 <= hist["test"][None][metrics.W_F1][metrics.FRAME_LEVEL]["master"] <= 1.0
+    assert tr.optimizer.param_groups[0]["lr"] == 1e-3 * 0.5           # StepLR(step_size=2) after 3 epochs
+    # the device path refuses a CPU trainer instead of handing host pointers to a kernel
+    import pytest
+    with pytest.raises(ValueError):
+        tr.inference(loaders["valid"], aggregate="device")
