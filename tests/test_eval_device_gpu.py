@@ -144,3 +144,50 @@ def test_trainer_inference_device_and_host_aggregation_agree_on_the_hip_model():
     from feature_vs_text_compound_emotion_amd.eval_device import stitch_windows
     with pytest.raises(ValueError):
         stitch_windows(torch.zeros(2, 8, 7), [0, 5], 13)
+
+
+def test_device_eval_mixin_under_a_reference_shaped_trainer():
+    """``class Trainer(DeviceEvalMixin, GenericVideoTrainer)`` -- the mixin only needs what the REFERENCE's trainer
+    already has (self.model, self.device, self.number_classes, self.train_batch_size, self.args with window_length / hop_length /
+    model_name / amp: trainer.py:436-523,788-892).  A stand-in with exactly those attributes and the reference's call signatures
+    ``inference(dataloader)`` / ``inference_forward_windows(data)``."""
+    from types import SimpleNamespace
+
+    from feature_vs_text_compound_emotion_amd import synth
+    from feature_vs_text_compound_emotion_amd.lfan import LFAN
+    from feature_vs_text_compound_emotion_amd.trainer import DeviceEvalMixin
+
+    class GenericVideoTrainerStandIn:          # base/trainer.py:21-45,96-115: what __init__ leaves on the object
+        def __init__(self, **kwargs):
+            self.device, self.model_name = kwargs["device"], kwargs["model_name"]
+            self.model = kwargs["models"].to(self.device)
+            self.train_batch_size = kwargs["train_batch_size"]
+
+    class RefTrainer(DeviceEvalMixin, GenericVideoTrainerStandIn):
+        def __init__(self, **kwargs):
+            super().__init__(**kwargs)
+            self.args, self.number_classes = None, None
+
+    mods = ["vggish", "bert"]
+    sd = synth.lfan_state_dict(mods, n_cls=7, seed=9)
+    model = LFAN(backbone_settings={}, output_dim=7, task="CLASSIFICATION", modality=mods, example_length=8, kernel_size=5,
+                 tcn_channel=synth.TCN_CHANNELS, root_dir="", device="cuda")
+    model.init(load_backbone=False)
+    model.load_state_dict(sd, strict=True)
+    tr = RefTrainer(device="cuda", model_name="LFAN", models=model.eval(), train_batch_size=2)
+    tr.args = SimpleNamespace(window_length=8, hop_length=5, model_name="LFAN", amp=True)   # --amp: autocast around the forward
+    tr.number_classes = 7
+    g = torch.Generator().manual_seed(6)
+    loader = []
+    for v, (n, label) in enumerate([(8, 1), (29, 4), (11, 4)]):
+        X = {"vggish": torch.randn(1, 1, n, 128, generator=g), "bert": torch.randn(1, 1, n, 768, generator=g),
+             "EXPR_continuous_label": torch.full((1, n, 1), float(label))}
+        loader.append((X, [f"v{v}"], [n], [np.arange(n)]))
+    perf_d, pv_d = tr.inference(loader)                    # the reference's signature and return value
+    tr.eval_aggregate = "host"
+    perf_h, pv_h = tr.inference(loader)
+    _same(perf_d, perf_h)
+    assert set(pv_d) == set(pv_h) == {"v0", "v1", "v2"}
+    for k in pv_h:
+        assert pv_d[k]["logits"].shape == pv_h[k]["logits"].shape and np.abs(pv_d[k]["logits"] - pv_h[k]["logits"]).max() < 1e-5
+        assert np.array_equal(pv_d[k]["labels"], pv_h[k]["labels"])
