@@ -260,7 +260,7 @@ class Workload:
         if "bert" in cfg["modalities"]:
             te = BertEncoderHIP()
             te.load_state_dict(synth.make_state_dict(synth.bert_spec(""), seed=31), strict=True)
-            if cfg["precision"] in NARROW:
+            if cfg["precision"] in NARROW or cfg["precision"] == "bf16x3":   # BERT's GEMMs in the encoder's arithmetic (fp32: exact)
                 te.precision = cfg["precision"]
         self.fx = MultimodalFeatureExtractor(ab, te if te is not None else torch.nn.Identity(), fps=32).to(dev).eval()
         secs = cfg["length"] / 32.0

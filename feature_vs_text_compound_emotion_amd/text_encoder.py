@@ -65,9 +65,10 @@ class BertEncoderHIP(nn.Module):
         for p in self.parameters():
             p.requires_grad = False
         self._packed, self._key = None, None
-        # "fp32": exact fp32 MFMA GEMMs; "bf16" / "fp16": the GEMM operands (activations and weights) as one 16-bit plane, one
-        # MFMA per product, fp32 accumulate -- what autocast does to nn.Linear (the reference's --amp recipe); attention,
-        # LayerNorm, GELU, residuals and the hidden-state sum stay fp32
+        # "fp32": exact fp32 MFMA GEMMs; "bf16x3": split hi / lo bf16 operands, three MFMAs per product (<= 2^-15 relative per
+        # product, 5x the fp32 matrix rate -- what VGGish and IR-50 run by default); "bf16" / "fp16": the GEMM operands
+        # (activations and weights) as one 16-bit plane, one MFMA per product, fp32 accumulate -- what autocast does to
+        # nn.Linear (the reference's --amp recipe); attention, LayerNorm, GELU, residuals and the hidden-state sum stay fp32
         self.precision = "fp32"
         self._packed_n16 = None
 
@@ -85,11 +86,13 @@ class BertEncoderHIP(nn.Module):
         return self._packed
 
     def _pack_n16(self, dtype):
+        """``dtype``: torch.bfloat16 / torch.float16 (one plane per weight) or "split" (hi / lo bf16 planes: bf16x3)."""
         packed = self._pack()
         if self._packed_n16 is None or self._packed_n16[0] != (dtype, self._key):
+            conv = ops.split_bf16 if dtype == "split" else (lambda w: ops.to_n16(w, dtype))
             layers = []
             for (wqkv, _), L in zip(packed, self.encoder.layer):
-                layers.append(tuple(ops.to_n16(w.detach().contiguous(), dtype) for w in
+                layers.append(tuple(conv(w.detach().contiguous()) for w in
                                     (wqkv, L.attention.output.dense.weight, L.intermediate.dense.weight, L.output.dense.weight)))
             self._packed_n16 = ((dtype, self._key), layers)
         return self._packed_n16[1]
@@ -99,6 +102,9 @@ class BertEncoderHIP(nn.Module):
         """y = act(x @ w^T + bias) + residual with narrow operands: x [rows, K] fp32 is rounded once, the result is fp32."""
         rows, k = x.shape
         r = None if residual is None else residual.view(rows, 1, 1, -1)
+        if isinstance(w16, ops.Split):      # bf16x3: both operands as split tensors
+            return ops.conv2d_b3(ops.split_bf16(x).view(rows, 1, 1, k), w16, 1, 1, bias=bias, act1=act, residual=r, out_f32=True,
+                                 out_split=False)["y"].view(rows, -1)
         return ops.conv2d_n16(ops.to_n16(x, w16.dtype).view(rows, 1, 1, k), w16, 1, 1, bias=bias, act1=act, residual=r,
                               out_f32=True, out_n16=False)["y"].view(rows, -1)
 
@@ -130,9 +136,10 @@ class BertEncoderHIP(nn.Module):
         n_layers = len(self.encoder.layer)
         if last_n_sum > n_layers:
             total = x.clone()
-        if self.precision not in ("fp32", "bf16", "fp16"):
+        if self.precision not in ("fp32", "bf16x3", "bf16", "fp16"):
             raise ValueError(f"unknown precision {self.precision!r}")
-        n16 = None if self.precision == "fp32" else self._pack_n16(torch.bfloat16 if self.precision == "bf16" else torch.float16)
+        n16 = None if self.precision == "fp32" else self._pack_n16(
+            {"bf16x3": "split", "bf16": torch.bfloat16, "fp16": torch.float16}[self.precision])
         for i, L in enumerate(self.encoder.layer):
             wqkv, bqkv = packed[i]
             if n16 is not None:
