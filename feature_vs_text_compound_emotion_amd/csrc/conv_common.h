@@ -46,6 +46,17 @@ __host__ __device__ __forceinline__ int s2d_row(int m, int ho, int wo, int Wo) {
     return (m - ho * Wo - wo) + 4 * ((ho >> 1) * (Wo >> 1) + (wo >> 1)) + 3 - 2 * (ho & 1) - (wo & 1);
 }
 
+// Division of block / pixel indices by launch constants (the kernels' prologues: an emulated 32-bit division is ~25
+// instructions, and a 16x16-patch block needs four of them before it can issue its first load).  magic = 2^32 / d + 1 makes
+// umulhi(x, magic) the quotient or the quotient + 1 for every 32-bit x; one compare corrects it.
+struct FastDiv { unsigned d, magic; };
+inline FastDiv make_fastdiv(unsigned d) { return FastDiv{d, d > 1 ? (unsigned)((1ull << 32) / d) + 1u : 0u}; }
+__device__ __forceinline__ unsigned fdiv(unsigned x, const FastDiv f) {
+    if (f.d == 1) return x;
+    const unsigned q = __umulhi(x, f.magic);
+    return q - (q * f.d > x ? 1u : 0u);
+}
+
 template <int I> struct IdxC { static constexpr int v = I; };
 template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (N > 0) {
@@ -208,7 +219,7 @@ __device__ __forceinline__ void epilogue_store4(const ConvArgs &p, int m, int c,
 // EpiCtx decides ONCE per launch (uniformly) whether that subset applies, keeps the thread's per-channel constants in
 // registers (no loads in the row loop besides the residual: a load's vmcnt wait would also wait for the previous rows'
 // stores), and epi_store4 is then ~40 instructions; anything else falls back to epilogue_store4.
-__device__ __forceinline__ int epi_mode(const ConvArgs &p);
+__host__ __device__ __forceinline__ int epi_mode(const ConvArgs &p);
 
 struct EpiCtx {
     bool fast;
@@ -372,7 +383,7 @@ __device__ __forceinline__ void epi_store4_direct(const ConvArgs &p, bool fast, 
 // only in waves that hold a border pixel.
 enum { EPI_GENERIC = 0, EPI_RAW_F32, EPI_RAW_N16, EPI_B9_PRELU_SPLIT, EPI_B9_PRELU_N16, EPI_BIAS_RES_SPLIT, EPI_BIAS_RES_N16 };
 
-__device__ __forceinline__ int epi_mode(const ConvArgs &p) {
+__host__ __device__ __forceinline__ int epi_mode(const ConvArgs &p) {
     if ((p.Cout & 3) || p.y_ld != p.Cout || p.act2 != CER_ACT_NONE || p.mask || p.aux || p.y2_hi || p.res) return EPI_GENERIC;
     const bool same_res = p.res_hi && p.res_stride == 1 && p.Hr == p.Ho && p.Wr == p.Wo;
     if (!p.bias && !p.bias9 && p.act1 == CER_ACT_NONE && !p.res_hi) {
@@ -452,5 +463,125 @@ __device__ __forceinline__ void epi_row(const ConvArgs &p, const EpiCtx &e, int 
         epi_row_core<MODE>(p, e.aa, b, m, c, v);
     }
 }
+
+// ---- direct epilogue: accumulators -> global memory without the LDS round trip ----
+// In-kernel stamps of the 64 -> 64 @224x224 launch (tools/exp_stamp.py, profiles/round3_stamps_*.txt): of a block's 15.3 us,
+// 1.5 us went into writing the accumulators to LDS (ds_write_b128 runs at a third of the read rate), 3.2 us into the row
+// loop that read them back one 16-byte granule per iteration, and the K loop itself took 5.3 us.  The kernels whose wave tile
+// is [16 TC couts] x [16 TP pixels] with the WEIGHTS as the MFMA A operand hold, per lane, pixel l15 of every pixel tile and
+// rows 4 kg .. 4 kg + 3 of every cout tile.  Dealing the weight rows to the tile rows as
+//     tile a, tile row 4 kg + r   <->   cout  32 (a / 2) + 8 kg + 4 (a % 2) + r   of the wave's 16 TC couts
+// makes the accumulators of a tile PAIR 8 consecutive couts of one pixel: one 16-byte store per 16-bit plane (two for fp32),
+// and the four kg lanes of a pixel cover 64 contiguous bytes.  Only the permutation of the weight rows in the DMA addresses
+// differs from the plain layout; the per-cout batch statistics are reduced over the 16 pixel lanes with DPP row rotations.
+__host__ __device__ constexpr int epi_cout_of_row(int rho) {   // rho = 16 a + 4 kg + r, within a wave's span of 16 TC rows
+    return ((rho >> 5) << 5) + (((rho >> 2) & 3) << 3) + (((rho >> 4) & 1) << 2) + (rho & 3);
+}
+
+__device__ __forceinline__ float row16_sum(float v) {      // total of the 16 lanes of a DPP row, in every lane of the row
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x124, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x122, 0xf, 0xf, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x121, 0xf, 0xf, false));
+    return v;
+}
+
+template <int NARROW> __device__ __forceinline__ uint32_t pack2_n16(float a, float b) {
+    if constexpr (NARROW == CER_STORE_F16) return (uint32_t)f32_to_f16(a) | ((uint32_t)f32_to_f16(b) << 16);
+    else return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+}
+template <int NARROW> __device__ __forceinline__ void unpack8_n16(const uint4 q, float o[8]) {
+    const uint32_t w[4] = {q.x, q.y, q.z, q.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if constexpr (NARROW == CER_STORE_F16) {
+            o[2 * i] = f16_to_f32((uint16_t)(w[i] & 0xffffu));
+            o[2 * i + 1] = f16_to_f32((uint16_t)(w[i] >> 16));
+        } else {
+            o[2 * i] = __uint_as_float(w[i] << 16);
+            o[2 * i + 1] = __uint_as_float(w[i] & 0xffff0000u);
+        }
+    }
+}
+
+// One pixel x 8 consecutive couts (c .. c + 7 < Cout) of a specialised mode.  row: the output row (the pixel, or its
+// space-to-depth position); cs: the pixel's border case for the bias9 modes; aa / bb: PReLU slopes and the interior (or plain)
+// bias of the 8 couts.  NARROW: CER_STORE_BF16 / CER_STORE_F16 for the *_N16 modes, ignored otherwise.
+template <int MODE, int NARROW>
+__device__ __forceinline__ void epi_direct8(const ConvArgs &p, const float (&aa)[8], const float (&bb)[8], size_t row, int c, int cs,
+                                            const float (&v)[8]) {
+    static_assert(MODE != EPI_GENERIC, "specialised modes only");
+    const size_t off = row * (size_t)p.Cout + c;
+    float o[8];
+#pragma unroll
+    for (int t = 0; t < 8; ++t) o[t] = v[t];
+    if constexpr (MODE == EPI_B9_PRELU_SPLIT || MODE == EPI_B9_PRELU_N16) {
+        float b[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) b[t] = bb[t];
+        if (cs != 4) {   // a border pixel: its own bias row (L1 / L2 hits; one lane in eight at most on the 16x16 patches)
+            const float4 q0 = *reinterpret_cast<const float4 *>(p.bias9 + (size_t)cs * p.Cout + c);
+            const float4 q1 = *reinterpret_cast<const float4 *>(p.bias9 + (size_t)cs * p.Cout + c + 4);
+            b[0] = q0.x; b[1] = q0.y; b[2] = q0.z; b[3] = q0.w; b[4] = q1.x; b[5] = q1.y; b[6] = q1.z; b[7] = q1.w;
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            o[t] += b[t];
+            o[t] = o[t] >= 0.f ? o[t] : o[t] * aa[t];
+        }
+    }
+    if constexpr (MODE == EPI_BIAS_RES_SPLIT || MODE == EPI_BIAS_RES_N16) {
+        float rr[8];
+        if constexpr (MODE == EPI_BIAS_RES_N16) {
+            unpack8_n16<NARROW>(*reinterpret_cast<const uint4 *>(p.res_hi + off), rr);
+        } else {
+            float lo[8];
+            unpack8_n16<CER_STORE_BF16>(*reinterpret_cast<const uint4 *>(p.res_hi + off), rr);
+            unpack8_n16<CER_STORE_BF16>(*reinterpret_cast<const uint4 *>(p.res_lo + off), lo);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) rr[t] += lo[t];
+        }
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o[t] = (o[t] + bb[t]) + rr[t];
+    }
+    if constexpr (MODE == EPI_RAW_F32) {
+        *reinterpret_cast<float4 *>(p.y + off) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4 *>(p.y + off + 4) = make_float4(o[4], o[5], o[6], o[7]);
+    } else if constexpr (MODE == EPI_RAW_N16 || MODE == EPI_B9_PRELU_N16 || MODE == EPI_BIAS_RES_N16) {
+        uint4 q;
+        q.x = pack2_n16<NARROW>(o[0], o[1]); q.y = pack2_n16<NARROW>(o[2], o[3]);
+        q.z = pack2_n16<NARROW>(o[4], o[5]); q.w = pack2_n16<NARROW>(o[6], o[7]);
+        *reinterpret_cast<uint4 *>(p.y_hi + off) = q;
+    } else {
+        uint16_t h[8], l[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) split_bf16(o[t], h[t], l[t]);
+        uint4 qh, ql;
+        qh.x = h[0] | ((uint32_t)h[1] << 16); qh.y = h[2] | ((uint32_t)h[3] << 16); qh.z = h[4] | ((uint32_t)h[5] << 16); qh.w = h[6] | ((uint32_t)h[7] << 16);
+        ql.x = l[0] | ((uint32_t)l[1] << 16); ql.y = l[2] | ((uint32_t)l[3] << 16); ql.z = l[4] | ((uint32_t)l[5] << 16); ql.w = l[6] | ((uint32_t)l[7] << 16);
+        *reinterpret_cast<uint4 *>(p.y_hi + off) = qh;
+        *reinterpret_cast<uint4 *>(p.y_lo + off) = ql;
+    }
+}
+
+// The slopes / bias of the lane's 8 couts starting at c (zeros where the mode does not use them or past Cout)
+template <int MODE>
+__device__ __forceinline__ void epi_direct_consts(const ConvArgs &p, int c, float (&aa)[8], float (&bb)[8]) {
+#pragma unroll
+    for (int t = 0; t < 8; ++t) aa[t] = bb[t] = 0.f;
+    if (c + 7 >= p.Cout) return;
+    const float *bias = nullptr;
+    if constexpr (MODE == EPI_B9_PRELU_SPLIT || MODE == EPI_B9_PRELU_N16) bias = p.bias9 + (size_t)4 * p.Cout;
+    if constexpr (MODE == EPI_BIAS_RES_SPLIT || MODE == EPI_BIAS_RES_N16) bias = p.bias;
+    if (bias) {
+        const float4 q0 = *reinterpret_cast<const float4 *>(bias + c), q1 = *reinterpret_cast<const float4 *>(bias + c + 4);
+        bb[0] = q0.x; bb[1] = q0.y; bb[2] = q0.z; bb[3] = q0.w; bb[4] = q1.x; bb[5] = q1.y; bb[6] = q1.z; bb[7] = q1.w;
+    }
+    if constexpr (MODE == EPI_B9_PRELU_SPLIT || MODE == EPI_B9_PRELU_N16) {
+        const float4 q0 = *reinterpret_cast<const float4 *>(p.alpha + c), q1 = *reinterpret_cast<const float4 *>(p.alpha + c + 4);
+        aa[0] = q0.x; aa[1] = q0.y; aa[2] = q0.z; aa[3] = q0.w; aa[4] = q1.x; aa[5] = q1.y; aa[6] = q1.z; aa[7] = q1.w;
+    }
+}
+
 
 }  // namespace cer

@@ -364,7 +364,7 @@ static int launch_n16(const ConvArgs &a, hipStream_t st) {
 // groups; window-resident kernels (conv_n16_patch.hip, 3x3 / stride 1 / pad 1): patches of 16x16 pixels (H, W % 16 == 0):
 // 71 = 64 couts (Cin == 64, 4 waves, two blocks per CU), 72 = 128 couts, 78 = 128 couts with ping-pong phases; 1-D windows of
 // 256 consecutive pixels (any image size with W <= 86): 73 = 64 couts, 76 = 128 couts with ping-pong phases, 77 = 64 couts,
-// Cin == 64, ONE window buffer, 4 waves (two blocks per CU).
+// Cin == 64, ONE window buffer, 4 waves (two blocks per CU); 79 = persistent 16x16-patch blocks for Cin == 64 (conv_n16_p64.hip).
 static bool patch_geometry(const cer_conv_desc *d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil_h == 1 && d->dil_w == 1 && d->pad_t == 1 && d->pad_l == 1 &&
            d->Ho == d->H && d->Wo == d->W && (d->H & 15) == 0 && (d->W & 15) == 0 && (d->Cin & 63) == 0 && d->split_k <= 1;
@@ -387,7 +387,8 @@ int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
     }
     if (tile == 0) {
         const long long t256 = (M + 255) / 256;
-        if (patch_geometry(d) && d->Cin == 64 && t256 * ((Cout + 63) / 64) >= 1024) tile = 71;
+        if (patch_geometry(d) && d->Cin == 64 && t256 * ((Cout + 63) / 64) >= 1024)
+            tile = ((Cout & 63) == 0 && Cout <= 256 && Cout != 192 && t256 >= 2048) ? 79 : 71;   // 79: persistent blocks (conv_n16_p64.hip)
         else if (patch_geometry(d) && Cout >= 128 && t256 * ((Cout + 127) / 128) >= 512) tile = d->Cin >= 128 ? 78 : 72;  // 78: ping-pong
         else if (win_geometry(d) && t256 >= 64) {
             // one block per CU (the windows fill the LDS): whole rounds of 256 blocks; a 128-cout block does twice the work of
@@ -410,7 +411,7 @@ int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         case 65: bm = 128; bn = 64; break;
         case 66: bm = 64; bn = 64; break;
         case 67: bm = 64; bn = 128; break;
-        case 71: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels
+        case 71: case 79: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels (79: persistent blocks)
         case 72: case 78: bm = 256; bn = 128; break;   // (78: ping-pong phases)
         case 73: case 77: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels (77: Cin == 64, one window)
         case 76: bm = 256; bn = 128; break;   // (ping-pong phases)
@@ -429,6 +430,7 @@ int conv_n16_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 66: return launch_n16<64, 64, 2, 2>(a, st);
         case 67: return launch_n16<64, 128, 1, 4>(a, st);
         case 71: case 72: case 73: case 76: case 77: case 78: return conv_n16_patch_launch(tile, a, st);
+        case 79: return conv_n16_p64_launch(a, st);
         case 81: case 82: return conv_n16_s2d_launch(tile, a, st);
         case 91: return launch_n16<256, 256, 2, 4, 2>(a, st);
         case 94: return launch_n16<128, 128, 2, 2, 2>(a, st);

@@ -24,12 +24,9 @@
 
 namespace cer {
 
-// slot = chunk ^ PATCH_F[window column], 3 bits per column (tools/check_swizzle.py: patch_table_constant())
-constexpr unsigned long long PATCH_F_TABLE = 0xd92dad912240ull;
-__device__ __forceinline__ int patch_f(int wx) { return (int)((PATCH_F_TABLE >> (3 * wx)) & 7ull); }
 
 template <int BN, int WP, int WC, int XBUFS, bool F16, bool PP>
-__global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArgs p) {
+__global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArgs p, PatchGeo geo) {
     constexpr int NW = WP * WC, NT = NW * 64;
     constexpr int PH = 16, PWD = 16, WW = 18, WROWS = 18 * 18;    // patch and window geometry
     constexpr int XPIECES = (WROWS + 7) / 8;                       // 41 one-KiB pieces (328 rows, the last 4 unused)
@@ -39,7 +36,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
     static_assert(BN % (8 * NW) == 0, "weight-slice pieces are dealt round-robin to the waves");
     constexpr int WQ = BN / (8 * NW);                               // weight pieces per wave and step
     constexpr int TP = PH / WP, TC = BN / (16 * WC);                // 16x16 MFMA tiles per wave: output rows x cout tiles
-    static_assert(PH % WP == 0 && XBUFS >= 1 && XBUFS <= 2 && (XBUFS == 1 || XPW <= 9), "geometry");
+    static_assert(PH % WP == 0 && XBUFS >= 1 && XBUFS <= 2 && (XBUFS == 1 || XPW <= 9) && TC % 2 == 0, "geometry");
     static_assert(!PP || (WP == 4 && WC == 2 && XBUFS == 2 && (BN / 16) % 4 == 0), "ping-pong: waves w and w + 4 share a SIMD and split the couts");
     constexpr int WOFF = XBUFS * XBYTES, SINK = WOFF + RING * WSLICE;  // LDS map: windows | weight ring | 1 KiB sink
     constexpr unsigned OOB = 0x80000000u;
@@ -58,48 +55,28 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_n = bid % p.tiles_n, patch = bid / p.tiles_n;
-    const int pxn = p.W / PWD, pyn = p.H / PH;
-    const int px = patch % pxn, py = (patch / pxn) % pyn, n = patch / (pxn * pyn);
+    const int patch = (int)fdiv((unsigned)bid, geo.tiles_n), tile_n = bid - patch * p.tiles_n;
+    const int prw = (int)fdiv((unsigned)patch, geo.pxn), px = patch - prw * (int)geo.pxn.d;
+    const int n = (int)fdiv((unsigned)prw, geo.pyn), py = prw - n * (int)geo.pyn.d;
     const int c0 = tile_n * BN;
     const int cin_steps = p.cin_steps;
 
-    // ---- DMA assignment ----
-    // window: wave w moves pieces w, w + NW, ...; in a piece lane l owns window row 8 * piece + l / 8 = (wy, wx), LDS slot
-    // l % 8, and fetches source chunk slot ^ PATCH_F[wx]; offsets are relative to the image's first pixel
+    // ---- DMA assignment ----  (stamps of the 64 -> 64 @224x224 launch, tools/exp_stamp.py: the block used to spend 2.9 us of its
+    // 13.7 on ~570 instructions of 64-bit address arithmetic and emulated divisions before its first load; everything below is
+    // 32-bit -- conv_n16_patch_ok bounds an image and a weight panel by 2^31 bytes -- and the weight slices, whose addresses
+    // need nothing of the patch, are issued before the window's addresses are computed)
     const int prow = lane >> 3, slot = lane & 7;
-    unsigned x_off[XPW];
-    bool x_real[XPW];
-#pragma unroll
-    for (int i = 0; i < XPW; ++i) {
-        const int q = wave + NW * i;
-        const int row = q * 8 + prow;
-        const int wy = row / WW, wx = row - wy * WW;
-        const int iy = py * PH - 1 + wy, ix = px * PWD - 1 + wx;
-        const bool inb = q < XPIECES && row < WROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        x_real[i] = q < XPIECES;
-        x_off[i] = inb ? (unsigned)(((size_t)iy * p.W + ix) * p.x_ld * 2 + ((slot ^ patch_f(wx)) << 4)) : OOB;
-    }
     unsigned w_off[WQ];
     int w_piece[WQ];
 #pragma unroll
     for (int i = 0; i < WQ; ++i) {
         // PP: the group's own cout half (BN / 16 pieces of 8 rows) dealt to its four waves; else all pieces over all waves
         w_piece[i] = PP ? (wave >> 2) * (BN / 16) + (wave & 3) + 4 * i : wave + NW * i;
-        const int row = w_piece[i] * 8 + prow;
-        w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ ((row >> 1) & 7)) << 3)) * 2) : OOB;
+        const int row = w_piece[i] * 8 + prow;                                          // LDS row of the slice
+        const int grow = row / (TC * 16) * (TC * 16) + epi_cout_of_row(row % (TC * 16));  // the cout it holds (conv_common.h)
+        w_off[i] = c0 + grow < p.Cout ? (unsigned)(grow * p.Kpad * 2) + (unsigned)((slot ^ ((row >> 1) & 7)) << 4) : OOB;
     }
-    const char *ximg = reinterpret_cast<const char *>(p.x_hi) + (size_t)n * p.H * p.W * p.x_ld * 2;
     const char *wpanel = reinterpret_cast<const char *>(p.w_hi) + (size_t)c0 * p.Kpad * 2;
-
-    // window piece i of chunk cc into window buffer cc % XBUFS (or a zero piece into the sink: keeps the per-step DMA
-    // count of a wave constant, which the counted vmcnt relies on)
-    auto issue_x = [&](int i, int cc) {
-        const bool real = x_real[i] && cc < cin_steps;
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ximg) + (size_t)cc * 128, 0, (int)OOB, 0x00020000);
-        unsigned char *dst = real ? smem + (XBUFS == 2 ? (cc & 1) * XBYTES : 0) + (wave + NW * i) * 1024 : smem + SINK;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (n_lds_ptr_t)dst, 16, (int)(real ? x_off[i] : OOB), 0, 0, 0);
-    };
     // weight slice (cc, tap) into ring slot `ring` (zeros into the sink past the end of the K loop)
     auto issue_w = [&](int cc, int tap, int ring) {
         const bool real = cc < cin_steps;
@@ -111,6 +88,38 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rw, (n_lds_ptr_t)dst, 16, (int)(real ? w_off[i] : OOB), 0, 0, 0);
         }
     };
+    issue_w(0, 0, 0);
+    issue_w(0, 1, 1);
+
+    // window: wave w moves pieces w, w + NW, ...; in a piece lane l owns window row 8 * piece + l / 8 = (wy, wx), LDS slot
+    // l % 8, and fetches source chunk slot ^ PATCH_F[wx]; offsets are relative to the image's first pixel
+    unsigned x_off[XPW];
+    bool x_real[XPW];
+    {
+        const int iy0 = py * PH - 1, ix0 = px * PWD - 1, pitch = p.x_ld * 2;
+#pragma unroll
+        for (int i = 0; i < XPW; ++i) {
+            const int q = wave + NW * i;
+            const int row = q * 8 + prow;
+            const int wy = row / WW, wx = row - wy * WW;
+            const int iy = iy0 + wy, ix = ix0 + wx;
+            const bool inb = q < XPIECES && row < WROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            const unsigned off = (unsigned)((iy * p.W + ix) * pitch) + (unsigned)((slot ^ patch_f(wx)) << 4);
+            x_real[i] = q < XPIECES;
+            x_off[i] = inb ? off : OOB;
+        }
+    }
+    const char *ximg = reinterpret_cast<const char *>(p.x_hi) + (size_t)n * p.H * p.W * p.x_ld * 2;
+    // window piece i of chunk cc into window buffer cc % XBUFS (or a zero piece into the sink: keeps the per-step DMA
+    // count of a wave constant, which the counted vmcnt relies on)
+    auto issue_x = [&](int i, int cc) {
+        const bool real = x_real[i] && cc < cin_steps;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<char *>(ximg) + (size_t)cc * 128, 0, (int)OOB, 0x00020000);
+        unsigned char *dst = real ? smem + (XBUFS == 2 ? (cc & 1) * XBYTES : 0) + (wave + NW * i) * 1024 : smem + SINK;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rx, (n_lds_ptr_t)dst, 16, (int)(real ? x_off[i] : OOB), 0, 0, 0);
+    };
+#pragma unroll
+    for (int i = 0; i < XPW; ++i) issue_x(i, 0);
 
     n_f32x4 acc[TC][TP];
 #pragma unroll
@@ -128,13 +137,9 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
 #pragma unroll
     for (int kw = 0; kw < 3; ++kw) bcol[kw] = (wp * WW + kw + l15) * 128 + ((kg ^ patch_f(kw + l15)) << 4);
 
-    // ---- prologue: the whole window of chunk 0, weight slices of steps 0 and 1 ----
-#pragma unroll
-    for (int i = 0; i < XPW; ++i) issue_x(i, 0);
-    issue_w(0, 0, 0);
-    issue_w(0, 1, 1);
+    // ---- prologue: the weight slices of steps 0 and 1 and the whole window of chunk 0 are in flight (issued above) ----
     if constexpr (PP) {
-        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(WQ) : "memory");   // the window and slice 0 (slice 1 may still be in flight)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // slices 0 / 1 and the window
         __builtin_amdgcn_s_barrier();
         if (wc == 1) __builtin_amdgcn_s_barrier();                  // group 1 runs one phase behind group 0
     }
@@ -154,7 +159,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
                 // (lgkmcnt(0): this wave's fragment reads of the previous step have returned before anyone's DMA may
                 // overwrite the slot / window they came from)
                 if (cc == 0 && tap == 0) {
-                    asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(WQ) : "memory");  // prologue: all but slice 1
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");            // prologue: the slices and the window
                 } else {
                     asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(pcnt) : "memory");
                 }
@@ -224,12 +229,89 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
             }
         });
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sink pieces of the last steps (zero fills: they return at once)
+
+    // ---- direct epilogue (the encoder's specialised modes): accumulators -> global memory, no LDS round trip ----
+    const int emode = epi_mode(p);
+    if (emode != EPI_GENERIC && (p.Cout & 7) == 0) {
+        constexpr int NARROW = F16 ? CER_STORE_F16 : CER_STORE_BF16;
+        const int cw = c0 + wc * TC * 16;              // the wave's first cout
+        float s1[TC / 2][8], s2[TC / 2][8];
+#pragma unroll
+        for (int j = 0; j < TC / 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) s1[j][t] = s2[j][t] = 0.f;
+        const int gx = px * PWD + l15;
+        const int rx = gx == 0 ? 0 : (gx == p.W - 1 ? 2 : 1);
+        epi_dispatch(emode, [&](auto MODE_) {
+            constexpr int MODE = decltype(MODE_)::v;
+            if constexpr (MODE != EPI_GENERIC) {
+                static_for<TC / 2>([&](auto J) {
+                    constexpr int j = decltype(J)::v;
+                    const int c = cw + j * 32 + kg * 8;
+                    float aa[8], bb[8];
+                    epi_direct_consts<MODE>(p, c, aa, bb);
+                    if (c + 7 < p.Cout) {
+                        static_for<TP>([&](auto B) {
+                            constexpr int b = decltype(B)::v;
+                            const int gy = py * PH + b * WP + wp;
+                            const int ry = gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1);
+                            const int m = (n * p.H + gy) * p.W + gx;
+                            const float v[8] = {acc[2 * j][b][0], acc[2 * j][b][1], acc[2 * j][b][2], acc[2 * j][b][3],
+                                                acc[2 * j + 1][b][0], acc[2 * j + 1][b][1], acc[2 * j + 1][b][2], acc[2 * j + 1][b][3]};
+#pragma unroll
+                            for (int t = 0; t < 8; ++t) {
+                                s1[j][t] += v[t];
+                                s2[j][t] += v[t] * v[t];
+                            }
+                            epi_direct8<MODE, NARROW>(p, aa, bb, (size_t)(p.y_s2d ? s2d_row(m, gy, gx, p.W) : m), c, 3 * ry + rx, v);
+                        });
+                    }
+                });
+            }
+        });
+        if constexpr (PP) {
+            if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
+        }
+        if (p.stats) {
+#pragma unroll
+            for (int j = 0; j < TC / 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    s1[j][t] = row16_sum(s1[j][t]);
+                    s2[j][t] = row16_sum(s2[j][t]);
+                }
+            __syncthreads();                            // every wave has left the K loop: the LDS is free
+            float *red = reinterpret_cast<float *>(smem_n16p);  // [WP][2][BN]
+            if (l15 == 0) {
+#pragma unroll
+                for (int j = 0; j < TC / 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        red[(wp * 2 + 0) * BN + wc * TC * 16 + j * 32 + kg * 8 + t] = s1[j][t];
+                        red[(wp * 2 + 1) * BN + wc * TC * 16 + j * 32 + kg * 8 + t] = s2[j][t];
+                    }
+            }
+            __syncthreads();
+            if (tid < BN && c0 + tid < p.Cout) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WP; ++w) {
+                    t1 += red[(w * 2 + 0) * BN + tid];
+                    t2 += red[(w * 2 + 1) * BN + tid];
+                }
+                p.stats[((size_t)patch * 2 + 0) * p.Cout + c0 + tid] = t1;
+                p.stats[((size_t)patch * 2 + 1) * p.Cout + c0 + tid] = t2;
+            }
+        }
+        return;
+    }
     if constexpr (PP) {
         if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sink pieces of the last steps
 
-    // ---- epilogue: accumulators -> LDS (fp32, 16-byte granules XOR-swizzled by the row) -> compact coalesced loop ----
+    // ---- staged epilogue (every other launch): accumulators -> LDS (fp32, 16-byte granules XOR-swizzled by the row) -> compact
+    // coalesced loop ----
     constexpr int G = BN / 4, RPI = NT / G;
     static_assert(NT % G == 0 && RPI % 16 == 0 && 256 * BN * 4 <= SINK, "whole patch rows of 16 pixels per loop iteration; one pass");
     float *Ct = reinterpret_cast<float *>(smem_n16p);
@@ -244,7 +326,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
         const int ml = (b * WP + wp) * 16 + l15;
         static_for<TC>([&](auto A) {
             constexpr int a = decltype(A)::v;
-            const int gg = (wc * TC + a) * 4 + kg;
+            const int gg = (wc * TC * 16 + epi_cout_of_row(a * 16 + kg * 4)) >> 2;   // the granule of the lane's 4 couts
             *reinterpret_cast<n_f32x4 *>(Ct + ml * BN + ((gg ^ (ml & 15)) << 2)) = acc[a][b];
         });
     });
@@ -316,7 +398,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
     static_assert(BN % (8 * NW) == 0, "weight-slice pieces are dealt round-robin to the waves");
     constexpr int WQ = BN / (8 * NW);
     constexpr int TP = BM / (16 * WP), TC = BN / (16 * WC);
-    static_assert((XBUFS == 1 || XPW <= 9) && TP >= 2 && (XBUFS == 2 || !PP), "geometry");
+    static_assert((XBUFS == 1 || XPW <= 9) && TP >= 2 && (XBUFS == 2 || !PP) && TC % 2 == 0, "geometry");
     static_assert(!PP || (WP == 4 && WC == 2 && (BN / 16) % 4 == 0), "ping-pong: waves w and w + 4 share a SIMD and split the couts");
     constexpr unsigned OOB = 0x80000000u;
     constexpr int NGRP = 2 * TP;
@@ -360,8 +442,9 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
     for (int i = 0; i < WQ; ++i) {
         // PP: the group's own cout half (BN / 16 pieces of 8 rows) dealt to its four waves; else all pieces over all waves
         w_piece[i] = PP ? (wave >> 2) * (BN / 16) + (wave & 3) + 4 * i : wave + NW * i;
-        const int row = w_piece[i] * 8 + prow;
-        w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ ((row >> 1) & 7)) << 3)) * 2) : OOB;
+        const int row = w_piece[i] * 8 + prow;                                          // LDS row of the slice
+        const int grow = row / (TC * 16) * (TC * 16) + epi_cout_of_row(row % (TC * 16));  // the cout it holds (conv_common.h)
+        w_off[i] = c0 + grow < p.Cout ? (unsigned)(((size_t)grow * p.Kpad + ((slot ^ ((row >> 1) & 7)) << 3)) * 2) : OOB;
     }
     // base of the window's first pixel; lanes whose pixel lies outside the tensor carry the out-of-range offset instead
     const char *xwin = reinterpret_cast<const char *>(p.x_hi) + wstart * (long long)p.x_ld * 2;
@@ -508,12 +591,105 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
             }
         });
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- direct epilogue (the encoder's specialised modes): accumulators -> global memory, no LDS round trip ----
+    const int emode = epi_mode(p);
+    if (emode != EPI_GENERIC && (p.Cout & 7) == 0) {
+        constexpr int NARROW = F16 ? CER_STORE_F16 : CER_STORE_BF16;
+        const int cw = c0 + wc * TC * 16;              // the wave's first cout
+        float s1[TC / 2][8], s2[TC / 2][8];
+#pragma unroll
+        for (int j = 0; j < TC / 2; ++j)
+#pragma unroll
+            for (int t = 0; t < 8; ++t) s1[j][t] = s2[j][t] = 0.f;
+        // the lane's pixel of every pixel tile: its output row and border case (from the tap mask: a missing (0, 1) / (2, 1) /
+        // (1, 0) / (1, 2) tap is the first / last image row / column)
+        size_t orow[TP];
+        int cs[TP];
+        bool live[TP];
+#pragma unroll
+        for (int b = 0; b < TP; ++b) {
+            const int m = m0 + prow0[b];
+            live[b] = m < p.M;
+            const unsigned bits = taps[b];
+            const int ry = !((bits >> 1) & 1u) ? 0 : (!((bits >> 7) & 1u) ? 2 : 1), rx = !((bits >> 3) & 1u) ? 0 : (!((bits >> 5) & 1u) ? 2 : 1);
+            cs[b] = 3 * ry + rx;
+            orow[b] = (size_t)m;
+            if (p.y_s2d && live[b]) {
+                const int r = m % (p.Ho * p.Wo);
+                const int ho = r / p.Wo;
+                orow[b] = (size_t)s2d_row(m, ho, r - ho * p.Wo, p.Wo);
+            }
+        }
+        epi_dispatch(emode, [&](auto MODE_) {
+            constexpr int MODE = decltype(MODE_)::v;
+            if constexpr (MODE != EPI_GENERIC) {
+                static_for<TC / 2>([&](auto J) {
+                    constexpr int j = decltype(J)::v;
+                    const int c = cw + j * 32 + kg * 8;
+                    float aa[8], bb[8];
+                    epi_direct_consts<MODE>(p, c, aa, bb);
+                    if (c + 7 < p.Cout) {
+                        static_for<TP>([&](auto B) {
+                            constexpr int b = decltype(B)::v;
+                            if (live[b]) {
+                                const float v[8] = {acc[2 * j][b][0], acc[2 * j][b][1], acc[2 * j][b][2], acc[2 * j][b][3],
+                                                    acc[2 * j + 1][b][0], acc[2 * j + 1][b][1], acc[2 * j + 1][b][2], acc[2 * j + 1][b][3]};
+#pragma unroll
+                                for (int t = 0; t < 8; ++t) {
+                                    s1[j][t] += v[t];
+                                    s2[j][t] += v[t] * v[t];
+                                }
+                                epi_direct8<MODE, NARROW>(p, aa, bb, orow[b], c, cs[b], v);
+                            }
+                        });
+                    }
+                });
+            }
+        });
+        if constexpr (PP) {
+            if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
+        }
+        if (p.stats) {
+#pragma unroll
+            for (int j = 0; j < TC / 2; ++j)
+#pragma unroll
+                for (int t = 0; t < 8; ++t) {
+                    s1[j][t] = row16_sum(s1[j][t]);
+                    s2[j][t] = row16_sum(s2[j][t]);
+                }
+            __syncthreads();                            // every wave has left the K loop: the LDS is free
+            float *red = reinterpret_cast<float *>(smem_n16p);  // [WP][2][BN]
+            if (l15 == 0) {
+#pragma unroll
+                for (int j = 0; j < TC / 2; ++j)
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        red[(wp * 2 + 0) * BN + wc * TC * 16 + j * 32 + kg * 8 + t] = s1[j][t];
+                        red[(wp * 2 + 1) * BN + wc * TC * 16 + j * 32 + kg * 8 + t] = s2[j][t];
+                    }
+            }
+            __syncthreads();
+            if (tid < BN && c0 + tid < p.Cout) {
+                float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+                for (int w = 0; w < WP; ++w) {
+                    t1 += red[(w * 2 + 0) * BN + tid];
+                    t2 += red[(w * 2 + 1) * BN + tid];
+                }
+                p.stats[((size_t)tile_m * 2 + 0) * p.Cout + c0 + tid] = t1;
+                p.stats[((size_t)tile_m * 2 + 1) * p.Cout + c0 + tid] = t2;
+            }
+        }
+        return;
+    }
     if constexpr (PP) {
         if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- epilogue: accumulators -> LDS (fp32, swizzled granules) -> compact coalesced loop over consecutive output pixels ----
+    // ---- staged epilogue (every other launch): accumulators -> LDS (fp32, swizzled granules) -> compact coalesced loop over
+    // consecutive output pixels ----
     constexpr int G = BN / 4, RPI = NT / G;
     static_assert(NT % G == 0, "one thread per granule");
     float *Ct = reinterpret_cast<float *>(smem_n16p);   // the launcher sizes the LDS for 256 * BN floats at least
@@ -528,7 +704,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
         const int ml = (b * WP + wp) * 16 + l15;
         static_for<TC>([&](auto A) {
             constexpr int a = decltype(A)::v;
-            const int gg = (wc * TC + a) * 4 + kg;
+            const int gg = (wc * TC * 16 + epi_cout_of_row(a * 16 + kg * 4)) >> 2;   // the granule of the lane's 4 couts
             *reinterpret_cast<n_f32x4 *>(Ct + ml * BN + ((gg ^ (ml & 15)) << 2)) = acc[a][b];
         });
     });
@@ -624,14 +800,15 @@ static int launch_patch(const ConvArgs &a, hipStream_t st) {
     constexpr int XPIECES = 41;
     const size_t lds = (size_t)XBUFS * XPIECES * 1024 + 3 * (size_t)BN * 128 + 1024;
     const dim3 grid(a.tiles_m * a.tiles_n, 1, 1), block(WP * WC * 64);
+    const PatchGeo geo{make_fastdiv((unsigned)a.tiles_n), make_fastdiv((unsigned)(a.W / 16)), make_fastdiv((unsigned)(a.H / 16))};
     if (a.narrow == CER_STORE_F16) {
         auto k = conv_n16_patch_kernel<BN, WP, WC, XBUFS, true, PP>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CER_LAUNCH(k, grid, block, lds, st, a);
+        CER_LAUNCH(k, grid, block, lds, st, a, geo);
     } else {
         auto k = conv_n16_patch_kernel<BN, WP, WC, XBUFS, false, PP>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CER_LAUNCH(k, grid, block, lds, st, a);
+        CER_LAUNCH(k, grid, block, lds, st, a, geo);
     }
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;

@@ -263,13 +263,13 @@ def test_bn_apply_narrow_io(dtype):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("tile,hw", [(76, 14), (78, 16), (72, 16), (91, 9), (73, 10), (71, 16)])
+@pytest.mark.parametrize("tile,hw", [(76, 14), (78, 16), (72, 16), (91, 9), (73, 10), (71, 16), (79, 48)])
 @pytest.mark.parametrize("kind", ["raw_n16", "b9_prelu_n16", "bias_res_n16"])
 def test_specialised_row_epilogues_on_every_narrow_kernel_family(kind, tile, hw, dtype):
     """The three narrow launch kinds of the encoder, each alone, on the window, patch and flat kernels: the narrow output must
     be the float64 result of the same (already rounded) operands, rounded once -- up to the fp32 accumulation."""
     from feature_vs_text_compound_emotion_amd import ops
-    cin, cout = 64, (64 if tile in (73, 71) else 128)
+    cin, cout = 64, (64 if tile in (73, 71, 79) else 128)
     n = 5
     g = torch.Generator().manual_seed(tile * 10 + len(kind))
     x = torch.randn(n, cin, hw, hw, generator=g).to(dtype)
@@ -301,6 +301,41 @@ def test_specialised_row_epilogues_on_every_narrow_kernel_family(kind, tile, hw,
                            tile=tile)
     got = r["n16"].float().cpu().permute(0, 3, 1, 2).double()
     assert ((got - ref).abs() <= ulp * ref.abs() + 3e-5).all(), ((got - ref).abs() - ulp * ref.abs()).max().item()
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("n,h,w,cout", [(3, 256, 256, 64), (3, 256, 256, 128), (1, 64, 80, 256), (7, 16, 16, 64)])
+@pytest.mark.parametrize("kind", ["raw_n16", "raw_f32", "b9_prelu_n16", "bias_res_n16", "b9_prelu_s2d"])
+def test_persistent_patch_kernel_equals_the_one_patch_per_block_kernel(kind, n, h, w, cout, dtype):
+    """Tile 79 (conv_n16_p64.hip: one block per CU walks its patches, the next window prefetched, the previous patch's
+    epilogue under the current patch's MFMAs) against tile 71 (validated against float64 above): the same MFMA order per
+    accumulator, so the outputs are bit-identical; the per-patch batch statistics are summed in another order.  Sizes: 768
+    patches (3 .. 6 per block, every body variant of the walk, two cout tiles), fewer patches than blocks, four cout tiles."""
+    from feature_vs_text_compound_emotion_amd import ops
+    cin = 64
+    g = torch.Generator().manual_seed(n * 3 + h + cout + len(kind))
+    x = torch.randn(n, h, w, cin, generator=g).to(dtype).cuda()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).to(dtype)
+    wd = ops.to_n16(ops.pack_conv_weight(wt.float().cuda()), dtype)
+    if kind == "raw_n16":
+        kw = dict(want_stats=True)
+    elif kind == "raw_f32":
+        kw = dict(want_stats=True, out_f32=True, out_n16=False)
+    elif kind.startswith("b9_prelu"):
+        kw = dict(bias9=torch.randn(9, cout, generator=g).cuda(), alpha=(torch.rand(cout, generator=g) * 0.3 + 0.1).cuda(),
+                  act1=ops.ACT_PRELU, y_s2d=kind.endswith("s2d"))
+    else:
+        kw = dict(bias=torch.randn(cout, generator=g).cuda(), residual=torch.randn(n, h, w, cout, generator=g).to(dtype).cuda())
+    a = ops.conv2d_n16(x, wd, 3, 3, pad=(1, 1), tile=71, **kw)
+    b = ops.conv2d_n16(x, wd, 3, 3, pad=(1, 1), tile=79, **kw)
+    key = "y" if kind == "raw_f32" else "n16"
+    assert torch.equal(a[key], b[key])
+    if "stats" in a and a["stats"] is not None:
+        sa, sb = a["stats"].double(), b["stats"].double()
+        assert tuple(sa.shape) == tuple(sb.shape)
+        assert (sa - sb).abs().max().item() <= 1e-5 * sa.abs().max().item()
+    with pytest.raises(RuntimeError, match="specialised epilogues"):     # both outputs at once is the generic epilogue
+        ops.conv2d_n16(x, wd, 3, 3, pad=(1, 1), tile=79, out_f32=True, out_n16=True)
 
 
 # ---- space-to-depth hand-over of the stride-2 units (narrow twins of the bf16x3 tests) ----

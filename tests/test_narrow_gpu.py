@@ -6,8 +6,12 @@ Bars (round 3: every bar states its origin and can fail).
 
 * Like-for-like yardstick: the reference's own narrow arithmetic is torch autocast (trainer.py:367); ``oracle.narrow``
   runs the fp32 oracle under ``torch.autocast("cpu", dtype)``.  Whole-model LOGITS, eval and train mode: the HIP narrow
-  result has to be closer to the fp32 oracle than that (factor 0.8; measured ~0.15 in eval, ~0.55 in train mode: autocast
-  also narrows the tail, the HIP modes only the encoder).  IR-50 EMBEDDINGS: the encoder is the same arithmetic class as
+  result has to be closer to the fp32 oracle than that (factor 0.8; measured ~0.15 in eval mode on the maximum; in train
+  mode the comparison is on the RMS over the logits -- measured 0.55 .. 0.6 -- because the MAXIMUM over the 512 .. 1024
+  logits of one rounding realisation is not a stable statistic: the same arithmetic with the batch-statistics sums taken
+  in another order (1e-7 relative) measured 2.8e-3 and 4.4e-3 at an unchanged RMS of 8.9e-4; the maximum is held to the
+  1.6 x spread factor against both the format floor and the yardstick: autocast also narrows the tail, the HIP modes only
+  the encoder).  IR-50 EMBEDDINGS: the encoder is the same arithmetic class as
   autocast (16-bit tensors, fp32 accumulate; on the CPU the two land within 8 % of each other), so the bar is 1.25 x the
   yardstick and 1.5 x the storage-only emulation -- two rounding realisations of one format.
 * Absolute, eval mode: SURVEY section 7's cfg5 bar -- |logit error| <= 2e-2 and argmax agreement -- for both storage types,
@@ -166,7 +170,8 @@ def test_cfg5_trimodal_64_frame_clips_8_classes(precision):
     loss.backward()
     with torch.no_grad():
         oref = lfan_forward(x, sd, MODS, train=True, backbone_train=True)
-        tyard = (autocast_lfan_forward(x, sd, MODS, DT[precision], train=True, backbone_train=True) - oref).abs().max().item()
+        ydiff = autocast_lfan_forward(x, sd, MODS, DT[precision], train=True, backbone_train=True) - oref
+        tyard, tyard_rms = ydiff.abs().max().item(), ydiff.pow(2).mean().sqrt().item()
         # the storage format's floor: the oracle's tail on the storage-only emulation of the embedding
         emb = ir50_forward_narrow_storage(x["video"].reshape(-1, 3, hw, hw), sd, "spatial.visual.backbone.", DT[precision])
         orig = oracle_lfan.ir50_forward
@@ -180,9 +185,10 @@ def test_cfg5_trimodal_64_frame_clips_8_classes(precision):
     terr, trms = diff.abs().max().item(), diff.pow(2).mean().sqrt().item()
     tagree = (out.detach().cpu().argmax(-1) == oref.argmax(-1)).float().mean().item()
     print(f"[narrow {precision}] cfg5 train forward: max |logit err| {terr:.2e} (rms {trms:.2e}; storage-only emulation {floor:.2e}, "
-          f"reference autocast arithmetic {tyard:.2e}), argmax agreement {tagree:.4f}, loss {loss.item():.6f} vs oracle {oloss.item():.6f}")
+          f"reference autocast arithmetic {tyard:.2e}, rms {tyard_rms:.2e}), argmax agreement {tagree:.4f}, loss {loss.item():.6f} vs oracle {oloss.item():.6f}")
     assert terr < FLOOR_FACTOR * floor              # module docstring
-    assert terr < YARDSTICK * tyard
+    assert trms < YARDSTICK * tyard_rms             # the RMS: the maximum of one rounding realisation moves by +-40 % (docstring)
+    assert terr < FLOOR_FACTOR * tyard
     assert tagree > 0.95
     assert abs(loss.item() - oloss.item()) < LOGIT_BAR[precision] / 4
     assert model.regressor.weight.grad is not None and torch.isfinite(model.regressor.weight.grad).all()
