@@ -28,11 +28,14 @@ namespace cer {
 constexpr unsigned long long B3_PATCH_F_TABLE = 0xaaa00a00ull;
 __device__ __forceinline__ int b3_patch_f(int wx) { return (int)((B3_PATCH_F_TABLE >> (2 * wx)) & 3ull); }
 
+// block -> (patch, cout tile) -> (image, patch row, patch column) through reciprocals of the launch constants (conv_common.h)
+struct B3PatchGeo { FastDiv tiles_n, pxn, pyn; };
+
 // SINGLE: 4 waves (WC = 1, each wave 64 pixels x 64 couts), ONE window buffer that is re-filled at every chunk boundary, the
 // single-phase step (reads two MFMA groups ahead, DMA between MFMA groups, one barrier per step): 67 KiB of LDS, so TWO blocks
 // share a CU and cover each other's window fetches and epilogue -- the K-short 64-cout layers.
 template <int BN, int WP, int WC, bool SINGLE>
-__global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs p) {
+__global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs p, B3PatchGeo geo) {
     constexpr int NW = WP * WC, NT = NW * 64;
     constexpr int PH = 16, PWD = 16, WW = 18, WROWS = 18 * 18;
     constexpr int XPP = (WROWS + 15) / 16;                        // 21 one-KiB pieces (16 rows of 64 bytes) per plane
@@ -43,7 +46,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
     static_assert(WPIECES % NW == 0, "weight-slice pieces are dealt round-robin to the waves");
     constexpr int WQ = WPIECES / NW;                              // weight pieces per wave and step
     constexpr int TP = PH / WP, TC = BN / (16 * WC);
-    static_assert(PH % WP == 0 && (SINGLE || XPW <= 9) && TP >= 2, "geometry");
+    static_assert(PH % WP == 0 && (SINGLE || XPW <= 9) && TP >= 2 && TC % 2 == 0, "geometry");
     static_assert(SINGLE ? WC == 1 : (WP == 4 && WC == 2 && (BN / 16) % 4 == 0), "ping-pong: waves w and w + 4 share a SIMD and split the couts");
     constexpr int WOFF = (SINGLE ? 1 : 2) * XBYTES, SINK = WOFF + 3 * WSLICE;    // LDS map: window(s) | weight ring | 1 KiB sink
     constexpr unsigned OOB = 0x80000000u;
@@ -61,25 +64,30 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_n = bid % p.tiles_n, patch = bid / p.tiles_n;
-    const int pxn = p.W / PWD, pyn = p.H / PH;
-    const int px = patch % pxn, py = (patch / pxn) % pyn, n = patch / (pxn * pyn);
+    const int patch = (int)fdiv((unsigned)bid, geo.tiles_n), tile_n = bid - patch * p.tiles_n;
+    const int prw = (int)fdiv((unsigned)patch, geo.pxn), px = patch - prw * (int)geo.pxn.d;
+    const int n = (int)fdiv((unsigned)prw, geo.pyn), py = prw - n * (int)geo.pyn.d;
     const int c0 = tile_n * BN;
     const int cin_steps = p.cin_steps;
 
-    // ---- DMA assignment: in a piece lane l owns row l / 4 (16 rows), LDS slot l % 4 ----
+    // ---- DMA assignment: in a piece lane l owns row l / 4 (16 rows), LDS slot l % 4.  32-bit address arithmetic
+    // (conv_b3_patch_ok bounds an image and a weight panel by 2^31 bytes): tools/exp_stamp.py measured 2.9 us of a block's life
+    // in the 64-bit / emulated-division version of this prologue on the narrow twin of this kernel ----
     const int prow = lane >> 2, slot = lane & 3;
     unsigned x_off[XPW];
     bool x_real[XPW];
+    {
+        const int iy0 = py * PH - 1, ix0 = px * PWD - 1, pitch = p.x_ld * 2;
 #pragma unroll
-    for (int i = 0; i < XPW; ++i) {
-        const int q = wave + NW * i;
-        const int row = q * 16 + prow;
-        const int wy = row / WW, wx = row - wy * WW;
-        const int iy = py * PH - 1 + wy, ix = px * PWD - 1 + wx;
-        const bool inb = q < XPP && row < WROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
-        x_real[i] = q < XPP;
-        x_off[i] = inb ? (unsigned)(((size_t)iy * p.W + ix) * p.x_ld * 2 + ((slot ^ b3_patch_f(wx)) << 4)) : OOB;
+        for (int i = 0; i < XPW; ++i) {
+            const int q = wave + NW * i;
+            const int row = q * 16 + prow;
+            const int wy = row / WW, wx = row - wy * WW;
+            const int iy = iy0 + wy, ix = ix0 + wx;
+            const bool inb = q < XPP && row < WROWS && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+            x_real[i] = q < XPP;
+            x_off[i] = inb ? (unsigned)((iy * p.W + ix) * pitch) + (unsigned)((slot ^ b3_patch_f(wx)) << 4) : OOB;
+        }
     }
     unsigned w_off[WQ];
     int w_plane[WQ], w_dst[WQ];
@@ -90,9 +98,10 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
         constexpr int PPL = SINGLE ? BN / 16 : BN / 32;             // pieces per plane in this wave's pool
         w_plane[i] = j / PPL;
         const int pc = (SINGLE ? 0 : (wave >> 2) * PPL) + j % PPL;  // piece (16 cout rows) within the plane
-        const int row = pc * 16 + prow;
+        const int row = pc * 16 + prow;                                                   // LDS row of the slice
+        const int grow = row / (TC * 16) * (TC * 16) + epi_cout_of_row(row % (TC * 16));  // the cout it holds (conv_common.h)
         w_dst[i] = w_plane[i] * WPL + pc * 1024;
-        w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ swz16((row >> 2) & 3)) << 3)) * 2) : OOB;
+        w_off[i] = c0 + grow < p.Cout ? (unsigned)(grow * p.Kpad * 2) + (unsigned)((slot ^ swz16((row >> 2) & 3)) << 4) : OOB;
     }
     const size_t img = (size_t)n * p.H * p.W * p.x_ld * 2;
     const char *xh = reinterpret_cast<const char *>(p.x_hi) + img, *xl = reinterpret_cast<const char *>(p.x_lo) + img;
@@ -244,12 +253,40 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
             }
         });
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sink pieces of the last steps (zero fills: they return at once)
+
+    // ---- direct epilogue (the encoder's specialised modes): accumulators -> global memory, no LDS round trip (conv_common.h) ----
+    const int emode = epi_mode(p);
+    if (emode != EPI_GENERIC && (p.Cout & 7) == 0) {
+        float s1[TC / 2][8], s2[TC / 2][8];
+        EpiPix epx[TP];
+        {
+            const int gx = px * PWD + l15;
+            const int rx = gx == 0 ? 0 : (gx == p.W - 1 ? 2 : 1);
+#pragma unroll
+            for (int b = 0; b < TP; ++b) {
+                const int gy = py * PH + b * WP + wp;
+                const int ry = gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1);
+                const int m = (n * p.H + gy) * p.W + gx;
+                epx[b] = EpiPix{true, (size_t)(p.y_s2d ? s2d_row(m, gy, gx, p.W) : m), 3 * ry + rx};
+            }
+        }
+        epi_dispatch(emode, [&](auto MODE_) {
+            constexpr int MODE = decltype(MODE_)::v;
+            if constexpr (MODE != EPI_GENERIC) epi_direct_stores<MODE, CER_STORE_BF16, TC, TP>(p, acc, c0 + wc * TC * 16, kg, epx, s1, s2);
+        });
+        if constexpr (!SINGLE) {
+            if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
+        }
+        if (p.stats) epi_direct_stats<TC, WP, BN>(p, s1, s2, reinterpret_cast<float *>(smem_b3p), wp, wc, kg, l15, tid, c0, (size_t)patch);
+        return;
+    }
     if constexpr (!SINGLE) {
         if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sink pieces of the last steps
 
-    // ---- epilogue: accumulators -> LDS (fp32, swizzled granules) -> compact coalesced loop, one patch row per iteration ----
+    // ---- staged epilogue (every other launch): accumulators -> LDS (fp32, swizzled granules) -> compact coalesced loop, one patch
+    // row per iteration ----
     constexpr int G = BN / 4, RPI = NT / G;
     static_assert(NT % G == 0 && RPI % 16 == 0 && 256 * BN * 4 <= SINK, "whole patch rows of 16 pixels per loop iteration; one pass");
     float *Ct = reinterpret_cast<float *>(smem_b3p);
@@ -264,7 +301,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
         const int ml = (b * WP + wp) * 16 + l15;
         static_for<TC>([&](auto A) {
             constexpr int a = decltype(A)::v;
-            const int gg = (wc * TC + a) * 4 + kg;
+            const int gg = (wc * TC * 16 + epi_cout_of_row(a * 16 + kg * 4)) >> 2;   // the granule of the lane's 4 couts
             *reinterpret_cast<f32x4 *>(Ct + ml * BN + ((gg ^ (ml & 15)) << 2)) = acc[a][b];
         });
     });
@@ -326,7 +363,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_patch_kernel(ConvArgs
 // ring, counted vmcnt, unrolled taps, ping-pong phases -- is the patch kernel's.
 // SINGLE: as in conv_b3_patch_kernel -- 4 waves, one window buffer re-filled per chunk, single-phase steps, two blocks per CU.
 template <int BN, int WP, int WC, bool SINGLE>
-__global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p, int NP) {
+__global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p, int NP, WinGeo geo) {
     constexpr int NW = WP * WC, NT = NW * 64, BM = 256;
     constexpr int NPMAX = 27;                                     // window pieces (16 rows) per plane the LDS can hold twice
     constexpr int XPW = (NPMAX + NW - 1) / NW;                    // window pieces per wave, plane and chunk (upper bound)
@@ -334,7 +371,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
     static_assert(WPIECES % NW == 0, "weight-slice pieces are dealt round-robin to the waves");
     constexpr int WQ = WPIECES / NW;
     constexpr int TP = BM / (16 * WP), TC = BN / (16 * WC);
-    static_assert((SINGLE || XPW <= 9) && TP >= 2, "geometry");
+    static_assert((SINGLE || XPW <= 9) && TP >= 2 && TC % 2 == 0, "geometry");
     static_assert(SINGLE ? WC == 1 : (WP == 4 && WC == 2 && (BN / 16) % 4 == 0), "ping-pong: waves w and w + 4 share a SIMD and split the couts");
     constexpr unsigned OOB = 0x80000000u;
     extern __shared__ __attribute__((aligned(16))) uint16_t smem_b3p[];
@@ -353,13 +390,13 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int tile_m = (int)fdiv((unsigned)bid, geo.tiles_n), tile_n = bid - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, c0 = tile_n * BN;
     const int cin_steps = p.cin_steps;
     const int rows_needed = BM + 2 * p.W + 2;
-    const long long wstart = (long long)m0 - p.W - 1;             // first window pixel (may be negative)
+    const int wstart = m0 - p.W - 1;                              // first window pixel (may be negative)
 
-    // ---- DMA assignment ----
+    // ---- DMA assignment (32-bit address arithmetic: conv_b3_win_ok bounds a window by 2^31 bytes, M = N H W is an int) ----
     const int prow = lane >> 2, slot = lane & 3;
     unsigned x_off[XPW];
     bool x_real[XPW];
@@ -367,10 +404,10 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
     for (int i = 0; i < XPW; ++i) {
         const int q = wave + NW * i;
         const int row = q * 16 + prow;
-        const long long pix = wstart + row;
-        const bool inb = q < NP && row < rows_needed && pix >= 0 && pix < (long long)p.M;
+        const int pix = wstart + row;
+        const bool inb = q < NP && row < rows_needed && pix >= 0 && pix < p.M;
         x_real[i] = q < NP;
-        x_off[i] = inb ? (unsigned)(((size_t)row * p.x_ld + ((slot ^ ((row & 4) >> 1)) << 3)) * 2) : OOB;
+        x_off[i] = inb ? (unsigned)(row * p.x_ld * 2) + (unsigned)((slot ^ ((row & 4) >> 1)) << 4) : OOB;
     }
     unsigned w_off[WQ];
     int w_plane[WQ], w_dst[WQ];
@@ -381,12 +418,13 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
         constexpr int PPL = SINGLE ? BN / 16 : BN / 32;             // pieces per plane in this wave's pool
         w_plane[i] = j / PPL;
         const int pc = (SINGLE ? 0 : (wave >> 2) * PPL) + j % PPL;  // piece (16 cout rows) within the plane
-        const int row = pc * 16 + prow;
+        const int row = pc * 16 + prow;                                                   // LDS row of the slice
+        const int grow = row / (TC * 16) * (TC * 16) + epi_cout_of_row(row % (TC * 16));  // the cout it holds (conv_common.h)
         w_dst[i] = w_plane[i] * WPL + pc * 1024;
-        w_off[i] = c0 + row < p.Cout ? (unsigned)(((size_t)row * p.Kpad + ((slot ^ swz16((row >> 2) & 3)) << 3)) * 2) : OOB;
+        w_off[i] = c0 + grow < p.Cout ? (unsigned)(grow * p.Kpad * 2) + (unsigned)((slot ^ swz16((row >> 2) & 3)) << 4) : OOB;
     }
     // 64-bit base of the window's first pixel (never dereferenced where it points outside the tensor: those lanes are OOB)
-    const long long wbase = wstart * (long long)p.x_ld * 2;
+    const long long wbase = (long long)wstart * p.x_ld * 2;
     const char *xh = reinterpret_cast<const char *>(p.x_hi) + wbase, *xl = reinterpret_cast<const char *>(p.x_lo) + wbase;
     const size_t wpan = (size_t)c0 * p.Kpad * 2;
     const char *wh = reinterpret_cast<const char *>(p.w_hi) + wpan, *wl = reinterpret_cast<const char *>(p.w_lo) + wpan;
@@ -430,12 +468,12 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
         const int m = m0 + pl;
         unsigned bits = 0;
         if (m < p.M) {
-            const int r = m % (p.H * p.W);
-            const int y = r / p.W, x = r - y * p.W;
-            int t = 0;
+            const int r = m - (int)fdiv((unsigned)m, geo.hw) * (int)geo.hw.d;
+            const int y = (int)fdiv((unsigned)r, geo.w), x = r - y * p.W;
+            const unsigned rowm = (y > 0 ? 1u : 0u) | 2u | (y < p.H - 1 ? 4u : 0u), colm = (x > 0 ? 1u : 0u) | 2u | (x < p.W - 1 ? 4u : 0u);
+#pragma unroll
             for (int kh = 0; kh < 3; ++kh)
-                for (int kw = 0; kw < 3; ++kw, ++t)
-                    if ((unsigned)(y + kh - 1) < (unsigned)p.H && (unsigned)(x + kw - 1) < (unsigned)p.W) bits |= 1u << t;
+                if ((rowm >> kh) & 1u) bits |= colm << (3 * kh);
         }
         taps[b] = bits;
     }
@@ -543,12 +581,43 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
             }
         });
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+
+    // ---- direct epilogue (the encoder's specialised modes): accumulators -> global memory, no LDS round trip (conv_common.h) ----
+    const int emode = epi_mode(p);
+    if (emode != EPI_GENERIC && (p.Cout & 7) == 0) {
+        float s1[TC / 2][8], s2[TC / 2][8];
+        // the lane's pixel of every pixel tile: its output row and border case (from the tap mask: a missing (0, 1) / (2, 1) /
+        // (1, 0) / (1, 2) tap is the first / last image row / column)
+        EpiPix epx[TP];
+#pragma unroll
+        for (int b = 0; b < TP; ++b) {
+            const int m = m0 + prow0[b];
+            const unsigned bits = taps[b];
+            const int ry = !((bits >> 1) & 1u) ? 0 : (!((bits >> 7) & 1u) ? 2 : 1), rx = !((bits >> 3) & 1u) ? 0 : (!((bits >> 5) & 1u) ? 2 : 1);
+            epx[b] = EpiPix{m < p.M, (size_t)m, 3 * ry + rx};
+            if (p.y_s2d && epx[b].live) {
+                const int r = m % (p.Ho * p.Wo);
+                const int ho = r / p.Wo;
+                epx[b].row = (size_t)s2d_row(m, ho, r - ho * p.Wo, p.Wo);
+            }
+        }
+        epi_dispatch(emode, [&](auto MODE_) {
+            constexpr int MODE = decltype(MODE_)::v;
+            if constexpr (MODE != EPI_GENERIC) epi_direct_stores<MODE, CER_STORE_BF16, TC, TP>(p, acc, c0 + wc * TC * 16, kg, epx, s1, s2);
+        });
+        if constexpr (!SINGLE) {
+            if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
+        }
+        if (p.stats) epi_direct_stats<TC, WP, BN>(p, s1, s2, reinterpret_cast<float *>(smem_b3p), wp, wc, kg, l15, tid, c0, (size_t)tile_m);
+        return;
+    }
     if constexpr (!SINGLE) {
         if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- epilogue: accumulators -> LDS (fp32, swizzled granules) -> compact coalesced loop over consecutive output rows ----
+    // ---- staged epilogue (every other launch): accumulators -> LDS (fp32, swizzled granules) -> compact coalesced loop over
+    // consecutive output rows ----
     constexpr int G = BN / 4, RPI = NT / G;
     static_assert(NT % G == 0, "one thread per granule");
     float *Ct = reinterpret_cast<float *>(smem_b3p);   // the launcher sizes the LDS for 256 * BN floats at least
@@ -563,7 +632,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_b3_win_kernel(ConvArgs p
         const int ml = (b * WP + wp) * 16 + l15;
         static_for<TC>([&](auto A) {
             constexpr int a = decltype(A)::v;
-            const int gg = (wc * TC + a) * 4 + kg;
+            const int gg = (wc * TC * 16 + epi_cout_of_row(a * 16 + kg * 4)) >> 2;   // the granule of the lane's 4 couts
             *reinterpret_cast<f32x4 *>(Ct + ml * BN + ((gg ^ (ml & 15)) << 2)) = acc[a][b];
         });
     });
@@ -635,7 +704,8 @@ static int launch_b3_win(const ConvArgs &a, hipStream_t st) {
     if (lds < (size_t)256 * BN * 4) lds = (size_t)256 * BN * 4;   // the epilogue's accumulator tile
     auto k = conv_b3_win_kernel<BN, WP, WC, SINGLE>;
     if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, 1), dim3(WP * WC * 64), lds, st, a, np);
+    const WinGeo geo{make_fastdiv((unsigned)a.tiles_n), make_fastdiv((unsigned)(a.H * a.W)), make_fastdiv((unsigned)a.W)};
+    CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, 1), dim3(WP * WC * 64), lds, st, a, np, geo);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }
@@ -645,7 +715,8 @@ static int launch_b3_patch(const ConvArgs &a, hipStream_t st) {
     const size_t lds = (size_t)(SINGLE ? 1 : 2) * 2 * 21 * 1024 + 3 * (size_t)2 * BN * 64 + 1024;
     auto k = conv_b3_patch_kernel<BN, WP, WC, SINGLE>;
     if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, 1), dim3(WP * WC * 64), lds, st, a);
+    const B3PatchGeo geo{make_fastdiv((unsigned)a.tiles_n), make_fastdiv((unsigned)(a.W / 16)), make_fastdiv((unsigned)(a.H / 16))};
+    CER_LAUNCH(k, dim3(a.tiles_m * a.tiles_n, 1, 1), dim3(WP * WC * 64), lds, st, a, geo);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }

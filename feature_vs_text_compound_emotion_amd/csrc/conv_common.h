@@ -57,6 +57,9 @@ __device__ __forceinline__ unsigned fdiv(unsigned x, const FastDiv f) {
     return q - (q * f.d > x ? 1u : 0u);
 }
 
+// block -> (pixel tile, cout tile), pixel -> (image row, column): the window kernels' launch constants
+struct WinGeo { FastDiv tiles_n, hw, w; };
+
 template <int I> struct IdxC { static constexpr int v = I; };
 template <int N, class F> __device__ __forceinline__ void static_for(F &&f) {
     if constexpr (N > 0) {
@@ -583,5 +586,75 @@ __device__ __forceinline__ void epi_direct_consts(const ConvArgs &p, int c, floa
     }
 }
 
+
+// The lane's pixel of one pixel tile: does it exist, its output row (the pixel, or its space-to-depth position), its border case
+struct EpiPix { bool live; size_t row; int cs; };
+
+// All accumulators of a wave tile [16 TC couts] x [16 TP pixels] -> global memory in a specialised MODE, and the lane's partial
+// batch statistics (sums over its TP pixels of the RAW conv results of its 8 TC / 2 couts).  cw: the wave's first cout.
+template <int MODE, int NARROW, int TC, int TP, class ACC>
+__device__ __forceinline__ void epi_direct_stores(const ConvArgs &p, const ACC (&acc)[TC][TP], int cw, int kg, const EpiPix (&px)[TP],
+                                                  float (&s1)[TC / 2][8], float (&s2)[TC / 2][8]) {
+    static_assert(TC % 2 == 0, "cout tiles come in pairs (epi_cout_of_row)");
+    static_for<TC / 2>([&](auto J) {
+        constexpr int j = decltype(J)::v;
+        const int c = cw + j * 32 + kg * 8;
+        float aa[8], bb[8];
+        epi_direct_consts<MODE>(p, c, aa, bb);
+#pragma unroll
+        for (int t = 0; t < 8; ++t) s1[j][t] = s2[j][t] = 0.f;
+        if (c + 7 < p.Cout) {
+            static_for<TP>([&](auto B) {
+                constexpr int b = decltype(B)::v;
+                if (px[b].live) {
+                    const float v[8] = {acc[2 * j][b][0], acc[2 * j][b][1], acc[2 * j][b][2], acc[2 * j][b][3],
+                                        acc[2 * j + 1][b][0], acc[2 * j + 1][b][1], acc[2 * j + 1][b][2], acc[2 * j + 1][b][3]};
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) {
+                        s1[j][t] += v[t];
+                        s2[j][t] += v[t] * v[t];
+                    }
+                    epi_direct8<MODE, NARROW>(p, aa, bb, px[b].row, c, px[b].cs, v);
+                }
+            });
+        }
+    });
+}
+
+// The block's batch statistics from the lanes' partial sums: DPP row sums over the 16 pixel lanes, the WP waves of a cout group
+// through LDS (red: [WP][2][BN] floats, free once every wave has left the K loop: the first barrier), one row of p.stats.
+template <int TC, int WP, int BN>
+__device__ __forceinline__ void epi_direct_stats(const ConvArgs &p, float (&s1)[TC / 2][8], float (&s2)[TC / 2][8], float *red, int wp, int wc,
+                                                 int kg, int l15, int tid, int c0, size_t stats_row) {
+#pragma unroll
+    for (int j = 0; j < TC / 2; ++j)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            s1[j][t] = row16_sum(s1[j][t]);
+            s2[j][t] = row16_sum(s2[j][t]);
+        }
+    __syncthreads();
+    if (l15 == 0) {
+#pragma unroll
+        for (int j = 0; j < TC / 2; ++j) {
+            float *d1 = red + (wp * 2 + 0) * BN + wc * TC * 16 + j * 32 + kg * 8, *d2 = d1 + BN;
+            *reinterpret_cast<float4 *>(d1) = make_float4(s1[j][0], s1[j][1], s1[j][2], s1[j][3]);
+            *reinterpret_cast<float4 *>(d1 + 4) = make_float4(s1[j][4], s1[j][5], s1[j][6], s1[j][7]);
+            *reinterpret_cast<float4 *>(d2) = make_float4(s2[j][0], s2[j][1], s2[j][2], s2[j][3]);
+            *reinterpret_cast<float4 *>(d2 + 4) = make_float4(s2[j][4], s2[j][5], s2[j][6], s2[j][7]);
+        }
+    }
+    __syncthreads();
+    if (tid < BN && c0 + tid < p.Cout) {
+        float t1 = 0.f, t2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WP; ++w) {
+            t1 += red[(w * 2 + 0) * BN + tid];
+            t2 += red[(w * 2 + 1) * BN + tid];
+        }
+        p.stats[(stats_row * 2 + 0) * p.Cout + c0 + tid] = t1;
+        p.stats[(stats_row * 2 + 1) * p.Cout + c0 + tid] = t2;
+    }
+}
 
 }  // namespace cer

@@ -12,9 +12,9 @@
 //   * two window buffers (2 x 41 KiB): the window of patch i + 1 is fetched by LDS-DMA during the first five taps of patch i;
 //   * no weight traffic, no ring, no barrier inside the K loop -- one block barrier per patch (window i + 1 has landed,
 //     everyone is done with window i);
-//   * two accumulator sets: the epilogue of patch i - 1 (direct stores from the accumulators, conv_common.h; the batch statistics
-//     through DPP row sums) is issued between the MFMAs of the last four taps of patch i, so the matrix pipes do not idle
-//     behind it; its stores are the wave's YOUNGEST vector-memory operations at the end of the patch, so the counted
+//   * two accumulator sets: the epilogue of patch i - 1 (direct stores from the accumulators, conv_common.h) is issued between
+//     the MFMAs of the last four taps of patch i, so the matrix pipes do not idle behind it; the batch statistics are ONE running
+//     sum per lane over all of the block's patches (the consumer sums the per-patch rows: all but one of the block's are zeros); its stores are the wave's YOUNGEST vector-memory operations at the end of the patch, so the counted
 //     vmcnt(stores) that waits for window i + 1 does not wait for them;
 //   * blocks of one XCD walk neighbouring patches at the same time (halo rows shared in that XCD's L2).
 // Launches whose epilogue is not one of the specialised modes (conv_common.h: epi_mode) go to conv_n16_patch_kernel<64>.
@@ -25,7 +25,7 @@ namespace cer {
 namespace {
 constexpr int P64_BN = 64, P64_NW = 4, P64_XPIECES = 41, P64_XBYTES = P64_XPIECES * 1024;
 constexpr int P64_WSLICE = P64_BN * 128, P64_WOFF = 2 * P64_XBYTES, P64_SINK = P64_WOFF + 9 * P64_WSLICE, P64_RED = P64_SINK + 1024;
-constexpr int P64_LDS = P64_RED + 2 * P64_NW * 2 * P64_BN * 4;   // 162 816 bytes of the 163 840
+constexpr int P64_LDS = P64_RED + P64_NW * 2 * P64_BN * 4;       // 160 768 bytes of the 163 840
 }  // namespace
 
 template <bool F16>
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(256, 1) void conv_n16_p64_kernel(ConvArgs p, PatchG
 
     const int emode = epi_mode(p);
     const int cw = c0;                                         // the wave's first cout (one cout group of 64)
-    float *red = reinterpret_cast<float *>(smem + RED);        // [2][WP][2][BN]
+    float *red = reinterpret_cast<float *>(smem + RED);        // [WP][2][BN]
 
     // ---- epilogue pieces of one patch: chunk (j, b) = cout pair j x output row b * 4 + wp; statistics; final sum ----
     // (Cout is a multiple of 64: every lane's 8 couts exist.  STATS: only the raw-output launches carry batch statistics)
@@ -143,16 +143,16 @@ __global__ __launch_bounds__(256, 1) void conv_n16_p64_kernel(ConvArgs p, PatchG
         }
         const float v[8] = {acc[2 * j][b][0], acc[2 * j][b][1], acc[2 * j][b][2], acc[2 * j][b][3],
                             acc[2 * j + 1][b][0], acc[2 * j + 1][b][1], acc[2 * j + 1][b][2], acc[2 * j + 1][b][3]};
-        if constexpr (STATS) {
+        if constexpr (STATS) {   // the BLOCK's running sums over all of its patches (see the walk)
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                s1[j][e] = b == 0 ? v[e] : s1[j][e] + v[e];
-                s2[j][e] = b == 0 ? v[e] * v[e] : s2[j][e] + v[e] * v[e];
+                s1[j][e] += v[e];
+                s2[j][e] += v[e] * v[e];
             }
         }
         epi_direct8<MODE, NARROW>(p, aa, bb, (size_t)(p.y_s2d ? s2d_row(m, gy, gx, p.W) : m), c, cs, v);
     };
-    auto stats_to_lds = [&](int par) {                         // the wave's totals over its 64 pixels -> red[par][wp]
+    auto stats_to_lds = [&](int par) {                         // the wave's totals over all its pixels -> red[par][wp]
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
@@ -191,6 +191,12 @@ __global__ __launch_bounds__(256, 1) void conv_n16_p64_kernel(ConvArgs p, PatchG
         constexpr bool HAS_PREV = decltype(HAS_PREV_)::v, STATS = decltype(STATS_)::v;
         unsigned xo[XPW];
         if (has_next) window_offsets(nxt, xo);
+        if constexpr (HAS_PREV && STATS) {
+            // The statistics consumer sums the [patches][2][Cout] rows: the block keeps ONE running sum per lane over all of its
+            // patches (no per-patch DPP reduction, LDS round trip or final sum), writes zeros into the rows of all its patches but
+            // the last, and its totals into that one.  (Issued here: older than the window DMA below, see the counted vmcnt.)
+            if (tid < 2 * BN) p.stats[((size_t)prv.id * 2 + (tid >> 6)) * p.Cout + c0 + (tid & 63)] = 0.f;
+        }
         const unsigned char *Xb = smem + cur * XBYTES;
         // fragments of a HALF tap (32 of the 64 channels), read one half tap ahead: 8 reads in flight behind 16 MFMAs
         n_u32x4 af[2][TC], bf[2][TP];
@@ -240,7 +246,6 @@ __global__ __launch_bounds__(256, 1) void conv_n16_p64_kernel(ConvArgs p, PatchG
                 }
             }
         });
-        if constexpr (HAS_PREV && STATS) stats_to_lds(it & 1);
         // window `nxt` has landed (the stores of the epilogue above are younger than every DMA piece and may stay in flight:
         // one store per chunk in the 16-bit modes, two in the fp32 mode, loads besides in the residual mode -> drain everything)
         __builtin_amdgcn_sched_barrier(0);
@@ -253,7 +258,6 @@ __global__ __launch_bounds__(256, 1) void conv_n16_p64_kernel(ConvArgs p, PatchG
         }
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (HAS_PREV && STATS) stats_final(it & 1, prv);
     };
 
     // ---- the walk ----
@@ -262,6 +266,12 @@ __global__ __launch_bounds__(256, 1) void conv_n16_p64_kernel(ConvArgs p, PatchG
         constexpr int MODE = decltype(MODE_)::v;
         constexpr bool STATS = decltype(STATS_)::v;
         float aa[2][8], bb[2][8];                               // PReLU slopes / bias of the lane's 16 couts: once per block
+        if constexpr (STATS) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s1[j][e] = s2[j][e] = 0.f;
+        }
         epi_direct_consts<MODE>(p, cw + kg * 8, aa[0], bb[0]);
         epi_direct_consts<MODE>(p, cw + 32 + kg * 8, aa[1], bb[1]);
         Patch cur = patch_of(kq), prv = cur, nxt = cur;
@@ -295,10 +305,10 @@ __global__ __launch_bounds__(256, 1) void conv_n16_p64_kernel(ConvArgs p, PatchG
             if (lastA) epi_chunk(MODE_, STATS_, IdxC<ch / 4>{}, IdxC<ch % 4>{}, accA, cur, aa[ch / 4], bb[ch / 4]);
             else epi_chunk(MODE_, STATS_, IdxC<ch / 4>{}, IdxC<ch % 4>{}, accB, cur, aa[ch / 4], bb[ch / 4]);
         });
-        if constexpr (STATS) {
-            stats_to_lds((it + 1) & 1);
+        if constexpr (STATS) {   // the block's totals into the row of its last patch
+            stats_to_lds(0);
             __syncthreads();
-            stats_final((it + 1) & 1, cur);
+            stats_final(0, cur);
         }
     };
     // (conv_n16_p64_ok: statistics come with the raw-output modes only)

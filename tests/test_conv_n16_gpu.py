@@ -331,9 +331,10 @@ def test_persistent_patch_kernel_equals_the_one_patch_per_block_kernel(kind, n, 
     key = "y" if kind == "raw_f32" else "n16"
     assert torch.equal(a[key], b[key])
     if "stats" in a and a["stats"] is not None:
-        sa, sb = a["stats"].double(), b["stats"].double()
-        assert tuple(sa.shape) == tuple(sb.shape)
-        assert (sa - sb).abs().max().item() <= 1e-5 * sa.abs().max().item()
+        # (the consumers sum the per-patch rows; the persistent kernel keeps one running sum per block and writes zero rows besides)
+        assert tuple(a["stats"].shape) == tuple(b["stats"].shape)
+        sa, sb = a["stats"].double().sum(0), b["stats"].double().sum(0)
+        assert (sa - sb).abs().max().item() <= 2e-6 * sa.abs().max().item() * max(1.0, (n * h * w / 4096) ** 0.5)
     with pytest.raises(RuntimeError, match="specialised epilogues"):     # both outputs at once is the generic epilogue
         ops.conv2d_n16(x, wd, 3, 3, pad=(1, 1), tile=79, out_f32=True, out_n16=True)
 

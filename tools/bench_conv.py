@@ -6,6 +6,9 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from feature_vs_text_compound_emotion_amd import _lib  # noqa: E402
+if os.environ.get("CER_EXP_LIB"):          # A/B runs against an experimental build (tools/exp_*.py): never set in product use
+    _lib.LIB_PATH = os.environ["CER_EXP_LIB"]
 from feature_vs_text_compound_emotion_amd import ops  # noqa: E402
 
 # (name, Cin, Cout, H, k, stride) for a 40x40 IR-50; H scales with --hw/40
@@ -32,6 +35,7 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--b3", action="store_true", help="bf16x3 kernel (split hi/lo operands)")
     ap.add_argument("--n16", choices=["bf16", "fp16"], default=None, help="narrow kernel (one 16-bit plane per operand)")
+    ap.add_argument("--stats", action="store_true", help="narrow path: request the batch-statistics rows (the conv2 launches of a training-mode unit)")
     ap.add_argument("--custom", default="", help="cin,cout,h,k,stride[;...]: these layers (h as given) instead of the IR-50 list")
     a = ap.parse_args()
     scale = a.hw / 40
@@ -53,7 +57,7 @@ def main():
             xs, ws = ops.to_n16(x, dt), ops.to_n16(w, dt)
             del x
             for tile in [int(t) for t in a.tiles.split(",")]:
-                run = lambda: ops.conv2d_n16(xs, ws, k, k, stride=stride, pad=(k // 2, k // 2), tile=tile)  # noqa: E731
+                run = lambda: ops.conv2d_n16(xs, ws, k, k, stride=stride, pad=(k // 2, k // 2), tile=tile, want_stats=a.stats)  # noqa: E731
                 try:
                     for _ in range(2):
                         run()
