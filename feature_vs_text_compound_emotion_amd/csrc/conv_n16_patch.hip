@@ -231,79 +231,31 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the sink pieces of the last steps (zero fills: they return at once)
 
-    // ---- direct epilogue (the encoder's specialised modes): accumulators -> global memory, no LDS round trip ----
+    // ---- direct epilogue (the encoder's specialised modes): accumulators -> global memory, no LDS round trip (conv_common.h) ----
     const int emode = epi_mode(p);
     if (emode != EPI_GENERIC && (p.Cout & 7) == 0) {
         constexpr int NARROW = F16 ? CER_STORE_F16 : CER_STORE_BF16;
-        const int cw = c0 + wc * TC * 16;              // the wave's first cout
         float s1[TC / 2][8], s2[TC / 2][8];
+        EpiPix epx[TP];
+        {
+            const int gx = px * PWD + l15;
+            const int rx = gx == 0 ? 0 : (gx == p.W - 1 ? 2 : 1);
 #pragma unroll
-        for (int j = 0; j < TC / 2; ++j)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) s1[j][t] = s2[j][t] = 0.f;
-        const int gx = px * PWD + l15;
-        const int rx = gx == 0 ? 0 : (gx == p.W - 1 ? 2 : 1);
+            for (int b = 0; b < TP; ++b) {
+                const int gy = py * PH + b * WP + wp;
+                const int ry = gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1);
+                const int m = (n * p.H + gy) * p.W + gx;
+                epx[b] = EpiPix{true, (size_t)(p.y_s2d ? s2d_row(m, gy, gx, p.W) : m), 3 * ry + rx};
+            }
+        }
         epi_dispatch(emode, [&](auto MODE_) {
             constexpr int MODE = decltype(MODE_)::v;
-            if constexpr (MODE != EPI_GENERIC) {
-                static_for<TC / 2>([&](auto J) {
-                    constexpr int j = decltype(J)::v;
-                    const int c = cw + j * 32 + kg * 8;
-                    float aa[8], bb[8];
-                    epi_direct_consts<MODE>(p, c, aa, bb);
-                    if (c + 7 < p.Cout) {
-                        static_for<TP>([&](auto B) {
-                            constexpr int b = decltype(B)::v;
-                            const int gy = py * PH + b * WP + wp;
-                            const int ry = gy == 0 ? 0 : (gy == p.H - 1 ? 2 : 1);
-                            const int m = (n * p.H + gy) * p.W + gx;
-                            const float v[8] = {acc[2 * j][b][0], acc[2 * j][b][1], acc[2 * j][b][2], acc[2 * j][b][3],
-                                                acc[2 * j + 1][b][0], acc[2 * j + 1][b][1], acc[2 * j + 1][b][2], acc[2 * j + 1][b][3]};
-#pragma unroll
-                            for (int t = 0; t < 8; ++t) {
-                                s1[j][t] += v[t];
-                                s2[j][t] += v[t] * v[t];
-                            }
-                            epi_direct8<MODE, NARROW>(p, aa, bb, (size_t)(p.y_s2d ? s2d_row(m, gy, gx, p.W) : m), c, 3 * ry + rx, v);
-                        });
-                    }
-                });
-            }
+            if constexpr (MODE != EPI_GENERIC) epi_direct_stores<MODE, NARROW, TC, TP>(p, acc, c0 + wc * TC * 16, kg, epx, s1, s2);
         });
         if constexpr (PP) {
             if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
         }
-        if (p.stats) {
-#pragma unroll
-            for (int j = 0; j < TC / 2; ++j)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    s1[j][t] = row16_sum(s1[j][t]);
-                    s2[j][t] = row16_sum(s2[j][t]);
-                }
-            __syncthreads();                            // every wave has left the K loop: the LDS is free
-            float *red = reinterpret_cast<float *>(smem_n16p);  // [WP][2][BN]
-            if (l15 == 0) {
-#pragma unroll
-                for (int j = 0; j < TC / 2; ++j)
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        red[(wp * 2 + 0) * BN + wc * TC * 16 + j * 32 + kg * 8 + t] = s1[j][t];
-                        red[(wp * 2 + 1) * BN + wc * TC * 16 + j * 32 + kg * 8 + t] = s2[j][t];
-                    }
-            }
-            __syncthreads();
-            if (tid < BN && c0 + tid < p.Cout) {
-                float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int w = 0; w < WP; ++w) {
-                    t1 += red[(w * 2 + 0) * BN + tid];
-                    t2 += red[(w * 2 + 1) * BN + tid];
-                }
-                p.stats[((size_t)patch * 2 + 0) * p.Cout + c0 + tid] = t1;
-                p.stats[((size_t)patch * 2 + 1) * p.Cout + c0 + tid] = t2;
-            }
-        }
+        if (p.stats) epi_direct_stats<TC, WP, BN>(p, s1, s2, reinterpret_cast<float *>(smem_n16p), wp, wc, kg, l15, tid, c0, (size_t)patch);
         return;
     }
     if constexpr (PP) {
@@ -390,7 +342,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_patch_kernel(ConvArg
 // XBUFS = 1: ONE window buffer (Cin == 64: a single chunk, nothing to prefetch) -- with 4 waves and 64 couts a block needs
 // NP + 25 KiB, so two blocks share a CU and overlap each other's window fetch and epilogue (the 64 -> 64 layers at 40 x 40).
 template <int BN, int WP, int WC, bool F16, bool PP, int XBUFS>
-__global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs p, int NP) {
+__global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs p, int NP, WinGeo geo) {
     constexpr int NW = WP * WC, NT = NW * 64, BM = 256;
     constexpr int NPMAX = 54;                                       // 8-row window pieces per buffer the LDS can hold twice (W <= 86)
     constexpr int XPW = (NPMAX + NW - 1) / NW;
@@ -418,12 +370,13 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
         const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tile_n = bid % p.tiles_n, tile_m = bid / p.tiles_n;
+    const int tile_m = (int)fdiv((unsigned)bid, geo.tiles_n), tile_n = bid - tile_m * p.tiles_n;
     const int m0 = tile_m * BM, c0 = tile_n * BN;
     const int cin_steps = p.cin_steps;
     const int rows_needed = BM + 2 * p.W + 2;
-    const long long wstart = (long long)m0 - p.W - 1;               // first window pixel (negative in the first tile)
+    const int wstart = m0 - p.W - 1;                                // first window pixel (negative in the first tile)
 
+    // (32-bit address arithmetic: conv_n16_win_ok bounds a window by 2^31 bytes and M = N H W is an int)
     const int prow = lane >> 3, slot = lane & 7;
     unsigned x_off[XPW];
     bool x_real[XPW];
@@ -431,10 +384,10 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
     for (int i = 0; i < XPW; ++i) {
         const int q = wave + NW * i;
         const int row = q * 8 + prow;
-        const long long pix = wstart + row;
-        const bool inb = q < NP && row < rows_needed && pix >= 0 && pix < (long long)p.M;
+        const int pix = wstart + row;
+        const bool inb = q < NP && row < rows_needed && pix >= 0 && pix < p.M;
         x_real[i] = q < NP;
-        x_off[i] = inb ? (unsigned)(((size_t)row * p.x_ld + ((slot ^ (row & 6)) << 3)) * 2) : OOB;
+        x_off[i] = inb ? (unsigned)(row * p.x_ld * 2) + (unsigned)((slot ^ (row & 6)) << 4) : OOB;
     }
     unsigned w_off[WQ];
     int w_piece[WQ];
@@ -447,7 +400,7 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
         w_off[i] = c0 + grow < p.Cout ? (unsigned)(((size_t)grow * p.Kpad + ((slot ^ ((row >> 1) & 7)) << 3)) * 2) : OOB;
     }
     // base of the window's first pixel; lanes whose pixel lies outside the tensor carry the out-of-range offset instead
-    const char *xwin = reinterpret_cast<const char *>(p.x_hi) + wstart * (long long)p.x_ld * 2;
+    const char *xwin = reinterpret_cast<const char *>(p.x_hi) + (long long)wstart * p.x_ld * 2;
     const char *wpanel = reinterpret_cast<const char *>(p.w_hi) + (size_t)c0 * p.Kpad * 2;
 
     auto issue_x = [&](int i, int cc) {
@@ -485,12 +438,12 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
         const int m = m0 + pl;
         unsigned bits = 0;
         if (m < p.M) {
-            const int r = m % (p.H * p.W);
-            const int y = r / p.W, x = r - y * p.W;
-            int t = 0;
+            const int r = m - (int)fdiv((unsigned)m, geo.hw) * (int)geo.hw.d;
+            const int y = (int)fdiv((unsigned)r, geo.w), x = r - y * p.W;
+            const unsigned rowm = (y > 0 ? 1u : 0u) | 2u | (y < p.H - 1 ? 4u : 0u), colm = (x > 0 ? 1u : 0u) | 2u | (x < p.W - 1 ? 4u : 0u);
+#pragma unroll
             for (int kh = 0; kh < 3; ++kh)
-                for (int kw = 0; kw < 3; ++kw, ++t)
-                    if ((unsigned)(y + kh - 1) < (unsigned)p.H && (unsigned)(x + kw - 1) < (unsigned)p.W) bits |= 1u << t;
+                if ((rowm >> kh) & 1u) bits |= colm << (3 * kh);
         }
         taps[b] = bits;
     }
@@ -593,95 +546,34 @@ __global__ __launch_bounds__(WP * WC * 64, 2) void conv_n16_win_kernel(ConvArgs 
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
-    // ---- direct epilogue (the encoder's specialised modes): accumulators -> global memory, no LDS round trip ----
+    // ---- direct epilogue (the encoder's specialised modes): accumulators -> global memory, no LDS round trip (conv_common.h) ----
     const int emode = epi_mode(p);
     if (emode != EPI_GENERIC && (p.Cout & 7) == 0) {
         constexpr int NARROW = F16 ? CER_STORE_F16 : CER_STORE_BF16;
-        const int cw = c0 + wc * TC * 16;              // the wave's first cout
         float s1[TC / 2][8], s2[TC / 2][8];
-#pragma unroll
-        for (int j = 0; j < TC / 2; ++j)
-#pragma unroll
-            for (int t = 0; t < 8; ++t) s1[j][t] = s2[j][t] = 0.f;
         // the lane's pixel of every pixel tile: its output row and border case (from the tap mask: a missing (0, 1) / (2, 1) /
         // (1, 0) / (1, 2) tap is the first / last image row / column)
-        size_t orow[TP];
-        int cs[TP];
-        bool live[TP];
+        EpiPix epx[TP];
 #pragma unroll
         for (int b = 0; b < TP; ++b) {
             const int m = m0 + prow0[b];
-            live[b] = m < p.M;
             const unsigned bits = taps[b];
             const int ry = !((bits >> 1) & 1u) ? 0 : (!((bits >> 7) & 1u) ? 2 : 1), rx = !((bits >> 3) & 1u) ? 0 : (!((bits >> 5) & 1u) ? 2 : 1);
-            cs[b] = 3 * ry + rx;
-            orow[b] = (size_t)m;
-            if (p.y_s2d && live[b]) {
+            epx[b] = EpiPix{m < p.M, (size_t)m, 3 * ry + rx};
+            if (p.y_s2d && epx[b].live) {
                 const int r = m % (p.Ho * p.Wo);
                 const int ho = r / p.Wo;
-                orow[b] = (size_t)s2d_row(m, ho, r - ho * p.Wo, p.Wo);
+                epx[b].row = (size_t)s2d_row(m, ho, r - ho * p.Wo, p.Wo);
             }
         }
         epi_dispatch(emode, [&](auto MODE_) {
             constexpr int MODE = decltype(MODE_)::v;
-            if constexpr (MODE != EPI_GENERIC) {
-                static_for<TC / 2>([&](auto J) {
-                    constexpr int j = decltype(J)::v;
-                    const int c = cw + j * 32 + kg * 8;
-                    float aa[8], bb[8];
-                    epi_direct_consts<MODE>(p, c, aa, bb);
-                    if (c + 7 < p.Cout) {
-                        static_for<TP>([&](auto B) {
-                            constexpr int b = decltype(B)::v;
-                            if (live[b]) {
-                                const float v[8] = {acc[2 * j][b][0], acc[2 * j][b][1], acc[2 * j][b][2], acc[2 * j][b][3],
-                                                    acc[2 * j + 1][b][0], acc[2 * j + 1][b][1], acc[2 * j + 1][b][2], acc[2 * j + 1][b][3]};
-#pragma unroll
-                                for (int t = 0; t < 8; ++t) {
-                                    s1[j][t] += v[t];
-                                    s2[j][t] += v[t] * v[t];
-                                }
-                                epi_direct8<MODE, NARROW>(p, aa, bb, orow[b], c, cs[b], v);
-                            }
-                        });
-                    }
-                });
-            }
+            if constexpr (MODE != EPI_GENERIC) epi_direct_stores<MODE, NARROW, TC, TP>(p, acc, c0 + wc * TC * 16, kg, epx, s1, s2);
         });
         if constexpr (PP) {
             if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary
         }
-        if (p.stats) {
-#pragma unroll
-            for (int j = 0; j < TC / 2; ++j)
-#pragma unroll
-                for (int t = 0; t < 8; ++t) {
-                    s1[j][t] = row16_sum(s1[j][t]);
-                    s2[j][t] = row16_sum(s2[j][t]);
-                }
-            __syncthreads();                            // every wave has left the K loop: the LDS is free
-            float *red = reinterpret_cast<float *>(smem_n16p);  // [WP][2][BN]
-            if (l15 == 0) {
-#pragma unroll
-                for (int j = 0; j < TC / 2; ++j)
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) {
-                        red[(wp * 2 + 0) * BN + wc * TC * 16 + j * 32 + kg * 8 + t] = s1[j][t];
-                        red[(wp * 2 + 1) * BN + wc * TC * 16 + j * 32 + kg * 8 + t] = s2[j][t];
-                    }
-            }
-            __syncthreads();
-            if (tid < BN && c0 + tid < p.Cout) {
-                float t1 = 0.f, t2 = 0.f;
-#pragma unroll
-                for (int w = 0; w < WP; ++w) {
-                    t1 += red[(w * 2 + 0) * BN + tid];
-                    t2 += red[(w * 2 + 1) * BN + tid];
-                }
-                p.stats[((size_t)tile_m * 2 + 0) * p.Cout + c0 + tid] = t1;
-                p.stats[((size_t)tile_m * 2 + 1) * p.Cout + c0 + tid] = t2;
-            }
-        }
+        if (p.stats) epi_direct_stats<TC, WP, BN>(p, s1, s2, reinterpret_cast<float *>(smem_n16p), wp, wc, kg, l15, tid, c0, (size_t)tile_m);
         return;
     }
     if constexpr (PP) {
@@ -775,14 +667,15 @@ static int launch_win(const ConvArgs &a, hipStream_t st) {
     size_t lds = (size_t)XBUFS * np * 1024 + 3 * (size_t)BN * 128 + 1024;
     if (lds < (size_t)256 * BN * 4) lds = (size_t)256 * BN * 4;   // the epilogue's accumulator tile
     const dim3 grid(a.tiles_m * a.tiles_n, 1, 1), block(WP * WC * 64);
+    const WinGeo geo{make_fastdiv((unsigned)a.tiles_n), make_fastdiv((unsigned)(a.H * a.W)), make_fastdiv((unsigned)a.W)};
     if (a.narrow == CER_STORE_F16) {
         auto k = conv_n16_win_kernel<BN, WP, WC, true, PP, XBUFS>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CER_LAUNCH(k, grid, block, lds, st, a, np);
+        CER_LAUNCH(k, grid, block, lds, st, a, np, geo);
     } else {
         auto k = conv_n16_win_kernel<BN, WP, WC, false, PP, XBUFS>;
         if (lds > 64 * 1024) CER_HIP_CHECK(hipFuncSetAttribute((const void *)k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CER_LAUNCH(k, grid, block, lds, st, a, np);
+        CER_LAUNCH(k, grid, block, lds, st, a, np, geo);
     }
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
