@@ -43,7 +43,7 @@ KERNEL_NAMES = {41: "cer::conv_b3_dma16_kernel<128, 128, 2, 2, 4, 2>", 42: "cer:
                 58: "cer::conv_b3_patch_kernel<128, 4, 2, false>", 59: "cer::conv_b3_patch_kernel<64, 4, 1, true>",
                 71: "cer::conv_n16_patch_kernel<64, 4, 1, 1, {f16}, false>", 72: "cer::conv_n16_patch_kernel<128, 4, 2, 2, {f16}, false>",
                 78: "cer::conv_n16_patch_kernel<128, 4, 2, 2, {f16}, true>",
-                73: "cer::conv_n16_win_kernel<64, 4, 2, {f16}, false, 2>", 75: "cer::conv_n16_winp_kernel<128, {f16}>", 76: "cer::conv_n16_win_kernel<128, 4, 2, {f16}, true, 2>",
+                73: "cer::conv_n16_win_kernel<64, 4, 2, {f16}, false, 2>", 76: "cer::conv_n16_win_kernel<128, 4, 2, {f16}, true, 2>",
                 77: "cer::conv_n16_win_kernel<64, 4, 1, {f16}, false, 1>", 79: "cer::conv_n16_p64_kernel<{f16}>",
                 81: "cer::conv_n16_s2d_kernel<64, {f16}>", 82: "cer::conv_n16_s2d_kernel<128, {f16}>",
                 91: "cer::conv_n16_kernel<256, 256, 2, 4, {f16}, 2>", 94: "cer::conv_n16_kernel<128, 128, 2, 2, {f16}, 2>",

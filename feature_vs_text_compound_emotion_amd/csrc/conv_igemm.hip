@@ -469,7 +469,6 @@ namespace cer {
 int conv_b3_launch(int tile, const ConvArgs &a, hipStream_t st);
 int conv_n16_launch(int tile, const ConvArgs &a, hipStream_t st);
 bool conv_n16_p64_ok(const ConvArgs &a);
-bool conv_n16_winp_ok(const ConvArgs &a);
 }  // namespace cer
 
 extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, void *workspace, size_t workspace_bytes,
@@ -547,9 +546,9 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
     if (n16) {
         tile = conv_n16_tile_dims(d, bm, bn, bk);
         if (!tile) return cer_set_error(CER_ERR_INVALID_ARG, "conv2d (narrow): unknown tile id (space-to-depth input: 81 / 82 only)");
-        if (d->y_s2d && tile != 71 && tile != 72 && tile != 78 && tile != 73 && tile != 76 && tile != 77 && tile != 79 && tile != 75)
+        if (d->y_s2d && tile != 71 && tile != 72 && tile != 78 && tile != 73 && tile != 76 && tile != 77 && tile != 79)
             return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow): y_s2d is written by the window / patch kernels only "
-                                                      "(cer_conv2d_n16_tile(desc) in {71, 72, 73, 75, 76, 77, 78, 79})");
+                                                      "(cer_conv2d_n16_tile(desc) in {71, 72, 73, 76, 77, 78, 79})");
         if (d->Cin % bk != 0 || (a.x_ld & 7))
             return cer_set_error(CER_ERR_UNSUPPORTED, "conv2d (narrow): Cin must be a multiple of 64 and x_ld of 8");
         esz = 2;
@@ -600,7 +599,6 @@ extern "C" int cer_conv2d_run(const cer_conv_desc *d, const cer_conv_io *io, voi
         // the picker chose the persistent Cin == 64 patch kernel from the geometry; a launch whose epilogue it does not take
         // (conv_n16_p64_ok) runs on the one-patch-per-block kernel of the same tile shape
         if (tile == 79 && d->tile == 0 && !conv_n16_p64_ok(a)) tile = 71;
-        if (tile == 75 && d->tile == 0 && !conv_n16_winp_ok(a)) tile = 76;
         rc = conv_n16_launch(tile, a, st);
     } else if (b3) {
         rc = conv_b3_launch(tile, a, st);

@@ -27,8 +27,6 @@ struct PatchGeo { FastDiv tiles_n, pxn, pyn; };
 int conv_n16_patch_launch(int tile, const ConvArgs &a, hipStream_t st);  // conv_n16_patch.hip
 int conv_n16_p64_launch(const ConvArgs &a, hipStream_t st);              // conv_n16_p64.hip: the persistent Cin == 64 patch kernel (tile 79)
 bool conv_n16_p64_ok(const ConvArgs &a);
-int conv_n16_winp_launch(const ConvArgs &a, hipStream_t st);             // conv_n16_winp.hip: the persistent ping-pong window kernel (tile 75)
-bool conv_n16_winp_ok(const ConvArgs &a);
 bool conv_n16_patch_ok(const ConvArgs &a, int tile);         // can the patch kernel `tile` take this conv?
 bool conv_n16_win_ok(const ConvArgs &a);                     // can the 1-D window kernels (tiles 73 / 74)?
 int conv_n16_s2d_launch(int tile, const ConvArgs &a, hipStream_t st);    // conv_n16_s2d.hip

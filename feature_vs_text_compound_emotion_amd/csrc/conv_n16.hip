@@ -364,7 +364,7 @@ static int launch_n16(const ConvArgs &a, hipStream_t st) {
 // groups; window-resident kernels (conv_n16_patch.hip, 3x3 / stride 1 / pad 1): patches of 16x16 pixels (H, W % 16 == 0):
 // 71 = 64 couts (Cin == 64, 4 waves, two blocks per CU), 72 = 128 couts, 78 = 128 couts with ping-pong phases; 1-D windows of
 // 256 consecutive pixels (any image size with W <= 86): 73 = 64 couts, 76 = 128 couts with ping-pong phases, 77 = 64 couts,
-// Cin == 64, ONE window buffer, 4 waves (two blocks per CU); 75 = 76 with persistent blocks (conv_n16_winp.hip); 79 = persistent 16x16-patch blocks for Cin == 64 (conv_n16_p64.hip).
+// Cin == 64, ONE window buffer, 4 waves (two blocks per CU); 79 = persistent 16x16-patch blocks for Cin == 64 (conv_n16_p64.hip).
 static bool patch_geometry(const cer_conv_desc *d) {
     return d->KH == 3 && d->KW == 3 && d->stride == 1 && d->dil_h == 1 && d->dil_w == 1 && d->pad_t == 1 && d->pad_l == 1 &&
            d->Ho == d->H && d->Wo == d->W && (d->H & 15) == 0 && (d->W & 15) == 0 && (d->Cin & 63) == 0 && d->split_k <= 1;
@@ -396,9 +396,6 @@ int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
             // measured per shape at 40x40, 80x80 and 224x224 input (tools/bench_conv.py): Cin == 64 -> the single-window tile (two
             // blocks per CU: 64 -> 64 @40x40 448 -> 565 TF/s, 64 -> 128 645 -> 677); else 128 couts with ping-pong phases, or 64
             tile = d->Cin == 64 ? 77 : (Cout > 64 ? 76 : 73);
-            // 75: the persistent form of 76 (conv_n16_winp.hip) when every block gets several tiles of one cout tile
-            const int tn = (Cout + 127) / 128;
-            if (tile == 76 && (Cout & 7) == 0 && (tn == 1 || tn == 2 || tn == 4) && t256 >= 1024) tile = 75;
         }
         else if (Cout <= 64) tile = t256 >= 512 ? 63 : ((M + 127) / 128 >= 256 ? 65 : 66);
         else if (Cout <= 128) tile = (M + 127) / 128 >= 256 ? 64 : 67;
@@ -417,7 +414,7 @@ int conv_n16_tile_dims(const cer_conv_desc *d, int &bm, int &bn, int &bk) {
         case 71: case 79: bm = 256; bn = 64; break;    // a 16x16 patch is 256 output pixels (79: persistent blocks)
         case 72: case 78: bm = 256; bn = 128; break;   // (78: ping-pong phases)
         case 73: case 77: bm = 256; bn = 64; break;    // 1-D window kernels (any image size): 256 consecutive pixels (77: Cin == 64, one window)
-        case 75: case 76: bm = 256; bn = 128; break;   // (ping-pong phases; 75: persistent blocks)
+        case 76: bm = 256; bn = 128; break;   // (ping-pong phases)
         case 81: bm = 256; bn = 64; break;    // 3x3 / stride 2 on a space-to-depth input (conv_n16_s2d.hip)
         case 82: bm = 256; bn = 128; break;
         default: return 0;
@@ -434,7 +431,6 @@ int conv_n16_launch(int tile, const ConvArgs &a, hipStream_t st) {
         case 67: return launch_n16<64, 128, 1, 4>(a, st);
         case 71: case 72: case 73: case 76: case 77: case 78: return conv_n16_patch_launch(tile, a, st);
         case 79: return conv_n16_p64_launch(a, st);
-        case 75: return conv_n16_winp_launch(a, st);
         case 81: case 82: return conv_n16_s2d_launch(tile, a, st);
         case 91: return launch_n16<256, 256, 2, 4, 2>(a, st);
         case 94: return launch_n16<128, 128, 2, 2, 2>(a, st);

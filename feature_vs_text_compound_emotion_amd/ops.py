@@ -332,7 +332,7 @@ def conv2d_n16_tile(n, h, w, cin, cout, kh, kw, stride, pad, x_s2d=False):
 
 # the window / patch kernels: their epilogues can store space-to-depth
 S2D_PRODUCER_TILES = (53, 56, 58, 59)
-S2D_PRODUCER_TILES_N16 = (71, 72, 73, 75, 76, 77, 78, 79)
+S2D_PRODUCER_TILES_N16 = (71, 72, 73, 76, 77, 78, 79)
 
 
 def s2d_k_order(cin, device, chunk=32):

@@ -339,41 +339,6 @@ def test_persistent_patch_kernel_equals_the_one_patch_per_block_kernel(kind, n, 
         ops.conv2d_n16(x, wd, 3, 3, pad=(1, 1), tile=79, out_f32=True, out_n16=True)
 
 
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("n,h,w,cin,cout", [(48, 56, 56, 128, 128), (48, 56, 56, 256, 256), (160, 40, 40, 128, 128), (3, 28, 28, 128, 512),
-                                            (700, 7, 5, 128, 128)])
-@pytest.mark.parametrize("kind", ["raw_n16", "raw_f32", "b9_prelu_n16", "bias_res_n16", "b9_prelu_s2d"])
-def test_persistent_window_kernel_equals_the_one_tile_per_block_kernel(kind, n, h, w, cin, cout, dtype):
-    """Tile 75 (conv_n16_winp.hip: one block per CU walks its 256-pixel tiles, the next tile's first window and slices ride in
-    the DMA slots the last chunk left empty) against tile 76: the same step pipeline per tile, so outputs AND the per-tile
-    statistics rows are bit-identical.  Sizes: 2 .. 5 tiles per block with one and two cout tiles, fewer tiles than blocks with
-    four cout tiles, tiles that span many tiny images (ragged last tile)."""
-    from feature_vs_text_compound_emotion_amd import ops
-    if kind == "b9_prelu_s2d" and (h % 2 or w % 2):
-        pytest.skip("space-to-depth stores need even sizes")
-    g = torch.Generator().manual_seed(n + h + cin + cout + len(kind))
-    x = torch.randn(n, h, w, cin, generator=g).to(dtype).cuda()
-    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (9 * cin) ** 0.5).to(dtype)
-    wd = ops.to_n16(ops.pack_conv_weight(wt.float().cuda()), dtype)
-    if kind == "raw_n16":
-        kw = dict(want_stats=True)
-    elif kind == "raw_f32":
-        kw = dict(want_stats=True, out_f32=True, out_n16=False)
-    elif kind.startswith("b9_prelu"):
-        kw = dict(bias9=torch.randn(9, cout, generator=g).cuda(), alpha=(torch.rand(cout, generator=g) * 0.3 + 0.1).cuda(),
-                  act1=ops.ACT_PRELU, y_s2d=kind.endswith("s2d"))
-    else:
-        kw = dict(bias=torch.randn(cout, generator=g).cuda(), residual=torch.randn(n, h, w, cout, generator=g).to(dtype).cuda())
-    a = ops.conv2d_n16(x, wd, 3, 3, pad=(1, 1), tile=76, **kw)
-    b = ops.conv2d_n16(x, wd, 3, 3, pad=(1, 1), tile=75, **kw)
-    key = "y" if kind == "raw_f32" else "n16"
-    assert torch.equal(a[key], b[key])
-    if a.get("stats") is not None:
-        assert torch.equal(a["stats"], b["stats"])
-    with pytest.raises(RuntimeError, match="specialised"):               # both outputs at once is the generic epilogue
-        ops.conv2d_n16(x, wd, 3, 3, pad=(1, 1), tile=75, out_f32=True, out_n16=True)
-
-
 # ---- space-to-depth hand-over of the stride-2 units (narrow twins of the bf16x3 tests) ----
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("n,cin,cout,h,w,tile", [(2, 64, 64, 32, 48, 71), (1, 128, 128, 16, 32, 72), (1, 128, 128, 16, 32, 78),
