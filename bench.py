@@ -86,7 +86,7 @@ def kernel_source_sha():
     """Identity of the code the traffic profiles were taken on: the conv / BatchNorm kernel sources."""
     h = hashlib.sha256()
     csrc = os.path.join(ROOT, "feature_vs_text_compound_emotion_amd", "csrc")
-    for f in ("conv_common.h", "conv_b3.hip", "conv_b3_patch.hip", "conv_b3_s2d.hip", "conv_n16.hip", "conv_n16_s2d.hip", "conv_n16_patch.hip", "conv_igemm.hip", "stem_conv.hip", "encoder_bn.hip"):
+    for f in ("conv_common.h", "conv_b3.hip", "conv_b3_patch.hip", "conv_b3_s2d.hip", "conv_n16.hip", "conv_n16_s2d.hip", "conv_n16_patch.hip", "conv_n16_p64.hip", "conv_igemm.hip", "stem_conv.hip", "encoder_bn.hip"):
         with open(os.path.join(csrc, f), "rb") as fh:
             h.update(fh.read())
     return h.hexdigest()[:16]
