@@ -373,7 +373,7 @@ class Workload:
                                       "durations on the launch stream over the timed steps",
                         "traffic": measured_traffic(cfg, dominant),
                         "traffic_note": "HBM bytes per launch of this kernel (rocprofv3 PMC, separate FETCH_SIZE / WRITE_SIZE passes, "
-                                        "FETCH x2 per the gfx950 correction, profiles/round2_traffic_*.json, keyed by configuration "
+                                        "FETCH x2 per the gfx950 correction, profiles/round3_traffic_*.json, keyed by configuration "
                                         "and kernel-source hash); algorithmic bytes per launch = input + output tensors + weights "
                                         "(+ residual)",
                         "algorithmic_bytes_per_launch": kd["algorithmic_bytes_per_launch"],
