@@ -63,6 +63,10 @@ _SIGNATURES = {
     "cer_pack_conv_weight": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cer_weight_norm_fwd": (c_int, [_P, _P, _P, _P, c_int, c_int, _P]),
     "cer_weight_norm_bwd": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "cer_weight_norm_fwd_packed": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "cer_weight_norm_bwd_partials": (c_int, [_P, c_int, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "cer_conv1d_wgrad_weight_norm_bwd": (c_int, [_P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P,
+                                                 _P, c_size_t, _P]),
     "cer_conv_wgrad_workspace_bytes": (c_size_t, [ctypes.c_longlong, c_int, c_int, c_int]),
     "cer_conv1d_wgrad": (c_int, [_P, c_int, _P, c_int, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_size_t, _P]),
     "cer_conv2d_wgrad": (c_int, [_P, _P, _P] + [c_int] * 12 + [_P, c_size_t, _P]),

@@ -26,8 +26,13 @@ __device__ __forceinline__ int wave_sum_int(int v) {
 // w = g * v / ||v||, one wave per output channel (row of E = Cin*k elements).
 // Reference: torch.nn.utils.weight_norm(dim=0) as applied at
 // models/temporal_convolutional_model.py:24,30.
+// Optionally ALSO the two packed layouts the conv kernels read (cer_pack_conv_weight's, for a [Cout][Cin][k] 1-D filter):
+// wp_f [Cout][Kpad_f] with column kh * Cin + c (forward) and wp_b [Cin][Kpad_b] with column (k - 1 - kh) * Cout + o (the
+// flipped, transposed data-gradient filter), zero padded -- the TCN re-normalises its weights every step, and two pack launches
+// per conv in the forward plus two in the backward were 48 of the tail's launches.
 __global__ void weight_norm_fwd_kernel(const float *__restrict__ v, const float *__restrict__ g,
-                                       float *__restrict__ w, float *__restrict__ norm, int rows, int E) {
+                                       float *__restrict__ w, float *__restrict__ norm, int rows, int E,
+                                       float *__restrict__ wp_f, float *__restrict__ wp_b, int k, int Kpad_f, int Kpad_b) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float *vr = v + (size_t)row * E;
@@ -35,23 +40,44 @@ __global__ void weight_norm_fwd_kernel(const float *__restrict__ v, const float 
     for (int i = lane; i < E; i += 64) s += vr[i] * vr[i];
     s = wave_sum(s);
     const float nrm = sqrtf(s), sc = g[row] / nrm;
-    for (int i = lane; i < E; i += 64) w[(size_t)row * E + i] = vr[i] * sc;
+    if (!wp_f) {
+        for (int i = lane; i < E; i += 64) w[(size_t)row * E + i] = vr[i] * sc;
+    } else {
+        const int cin = E / k;
+        for (int i = lane; i < E; i += 64) {
+            const float val = vr[i] * sc;
+            const int c = i / k, kh = i - c * k;
+            w[(size_t)row * E + i] = val;
+            wp_f[(size_t)row * Kpad_f + kh * cin + c] = val;
+            wp_b[(size_t)c * Kpad_b + (k - 1 - kh) * rows + row] = val;
+        }
+        for (int i = E + lane; i < Kpad_f; i += 64) wp_f[(size_t)row * Kpad_f + i] = 0.f;
+        const int padb = Kpad_b - k * rows;                    // padding columns of every wp_b row: dealt over the cout waves
+        for (int j = row * 64 + lane; j < cin * padb; j += rows * 64) wp_b[(size_t)(j / padb) * Kpad_b + k * rows + j % padb] = 0.f;
+    }
     if (lane == 0) norm[row] = nrm;
 }
 
-// dg = <dw, v>/||v||;  dv = g/||v|| * dw - g*<dw,v>/||v||^3 * v
+// dg = <dw, v>/||v||;  dv = g/||v|| * dw - g*<dw,v>/||v||^3 * v.  splits > 1: dw is the weight-gradient kernel's split-R
+// partial slabs [splits][rows * E], summed here in the fixed order 0 .. splits-1 (what wgrad_fold_kernel would have done).
 __global__ void weight_norm_bwd_kernel(const float *__restrict__ dw, const float *__restrict__ v,
                                        const float *__restrict__ g, const float *__restrict__ norm,
-                                       float *__restrict__ dv, float *__restrict__ dg, int rows, int E) {
+                                       float *__restrict__ dv, float *__restrict__ dg, int rows, int E, int splits) {
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (row >= rows) return;
     const float *vr = v + (size_t)row * E, *dr = dw + (size_t)row * E;
+    const size_t n = (size_t)rows * E;
+    auto grad = [&](int i) {
+        float d = dr[i];
+        for (int k = 1; k < splits; ++k) d += dr[(size_t)k * n + i];
+        return d;
+    };
     float s = 0.f;
-    for (int i = lane; i < E; i += 64) s += vr[i] * dr[i];
+    for (int i = lane; i < E; i += 64) s += vr[i] * grad(i);
     s = wave_sum(s);
     const float nrm = norm[row], gg = g[row];
     const float a = gg / nrm, b = gg * s / (nrm * nrm * nrm);
-    for (int i = lane; i < E; i += 64) dv[(size_t)row * E + i] = a * dr[i] - b * vr[i];
+    for (int i = lane; i < E; i += 64) dv[(size_t)row * E + i] = a * grad(i) - b * vr[i];
     if (lane == 0) dg[row] = s / nrm;
 }
 
@@ -614,7 +640,17 @@ extern "C" int cer_softmax_gate_bwd(const float *dout, const float *prob, const 
 
 extern "C" int cer_weight_norm_fwd(const float *v, const float *g, float *w, float *norm, int rows, int E, void *stream) {
     if (!v || !g || !w || !norm || rows <= 0 || E <= 0) return cer_set_error(CER_ERR_INVALID_ARG, "weight_norm_fwd: bad argument");
-    CER_LAUNCH(weight_norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, v, g, w, norm, rows, E);
+    CER_LAUNCH(weight_norm_fwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, v, g, w, norm, rows, E, (float *)nullptr, (float *)nullptr, 1, 0, 0);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+extern "C" int cer_weight_norm_fwd_packed(const float *v, const float *g, float *w, float *norm, float *wp_fwd, float *wp_dgrad, int Cout,
+                                          int Cin, int k, void *stream) {
+    if (!v || !g || !w || !norm || !wp_fwd || !wp_dgrad || Cout <= 0 || Cin <= 0 || k <= 0)
+        return cer_set_error(CER_ERR_INVALID_ARG, "weight_norm_fwd_packed: bad argument");
+    CER_LAUNCH(weight_norm_fwd_kernel, dim3((Cout + 3) / 4), dim3(256), 0, ST, v, g, w, norm, Cout, Cin * k, wp_fwd, wp_dgrad, k,
+               cer_conv_kpad(k, 1, Cin), cer_conv_kpad(k, 1, Cout));
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }
@@ -623,7 +659,16 @@ extern "C" int cer_weight_norm_bwd(const float *dw, const float *v, const float 
                                    float *dg, int rows, int E, void *stream) {
     if (!dw || !v || !g || !norm || !dv || !dg || rows <= 0 || E <= 0)
         return cer_set_error(CER_ERR_INVALID_ARG, "weight_norm_bwd: bad argument");
-    CER_LAUNCH(weight_norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, dw, v, g, norm, dv, dg, rows, E);
+    CER_LAUNCH(weight_norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, dw, v, g, norm, dv, dg, rows, E, 1);
+    CER_HIP_CHECK(hipGetLastError());
+    return CER_OK;
+}
+
+extern "C" int cer_weight_norm_bwd_partials(const float *dw_parts, int splits, const float *v, const float *g, const float *norm, float *dv,
+                                            float *dg, int rows, int E, void *stream) {
+    if (!dw_parts || splits <= 0 || !v || !g || !norm || !dv || !dg || rows <= 0 || E <= 0)
+        return cer_set_error(CER_ERR_INVALID_ARG, "weight_norm_bwd_partials: bad argument");
+    CER_LAUNCH(weight_norm_bwd_kernel, dim3((rows + 3) / 4), dim3(256), 0, ST, dw_parts, v, g, norm, dv, dg, rows, E, splits);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }

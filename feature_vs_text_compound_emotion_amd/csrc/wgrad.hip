@@ -145,7 +145,8 @@ __global__ void wgrad_fold_kernel(const float *__restrict__ part, float *__restr
     dw[i] = s;
 }
 
-static int wgrad_launch(WgradArgs a, float *dw, void *workspace, size_t workspace_bytes, hipStream_t st) {
+// splits_out != NULL: leave the split-R partial slabs in the workspace (the caller's next kernel sums them) and report how many
+static int wgrad_launch(WgradArgs a, float *dw, void *workspace, size_t workspace_bytes, hipStream_t st, int *splits_out = nullptr) {
     dim3 grid((a.Cout + WG_T - 1) / WG_T, (a.Cin + WG_T - 1) / WG_T, a.k);
     const size_t n = (size_t)a.Cout * a.Cin * a.k;
     int splits = wgrad_splits(a.R, (long long)grid.x * grid.y * grid.z);
@@ -154,7 +155,8 @@ static int wgrad_launch(WgradArgs a, float *dw, void *workspace, size_t workspac
     a.dw = splits > 1 ? (float *)workspace : dw;
     grid.z = a.k * splits;
     CER_LAUNCH(conv1d_wgrad_kernel, grid, dim3(256), 0, st, a);
-    if (splits > 1) CER_LAUNCH(wgrad_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float *)workspace, dw, n, splits);
+    if (splits_out) *splits_out = splits;
+    else if (splits > 1) CER_LAUNCH(wgrad_fold_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float *)workspace, dw, n, splits);
     CER_HIP_CHECK(hipGetLastError());
     return CER_OK;
 }
@@ -173,6 +175,27 @@ extern "C" int cer_conv1d_wgrad(const float *dz, int dz_ld, const float *x, int 
         return cer_set_error(CER_ERR_INVALID_ARG, "conv1d_wgrad: bad argument (R must be a multiple of L)");
     WgradArgs a{dz, x, dw, R, L, Cout, Cin, k, dil, dz_ld, x_ld, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     return wgrad_launch(a, dw, workspace, workspace_bytes, (hipStream_t)stream);
+}
+
+// The weight gradient of a weight-normed 1-D conv straight into (dv, dg): the weight-norm backward kernel (tail_kernels.hip) sums
+// the split-R partial slabs itself -- two launches instead of weight gradient + fold + weight-norm backward.  workspace: at least
+// max(cer_conv_wgrad_workspace_bytes(R, Cout, Cin, k), Cout * Cin * k floats).
+extern "C" int cer_weight_norm_bwd_partials(const float *dw_parts, int splits, const float *v, const float *g, const float *norm, float *dv,
+                                            float *dg, int rows, int E, void *stream);
+extern "C" int cer_conv1d_wgrad_weight_norm_bwd(const float *dz, int dz_ld, const float *x, int x_ld, int R, int L, int Cout, int Cin, int k,
+                                                int dil, const float *v, const float *g, const float *norm, float *dv, float *dg,
+                                                void *workspace, size_t workspace_bytes, void *stream) {
+    if (!dz || !x || !v || !g || !norm || !dv || !dg || R <= 0 || L <= 0 || Cout <= 0 || Cin <= 0 || k <= 0 || dil <= 0 || dz_ld < Cout ||
+        x_ld < Cin || (R % L) != 0)
+        return cer_set_error(CER_ERR_INVALID_ARG, "conv1d_wgrad_weight_norm_bwd: bad argument (R must be a multiple of L)");
+    const size_t n = (size_t)Cout * Cin * k;
+    if (!workspace || workspace_bytes < n * sizeof(float) || workspace_bytes < cer_conv_wgrad_workspace_bytes(R, Cout, Cin, k))
+        return cer_set_error(CER_ERR_WORKSPACE, "conv1d_wgrad_weight_norm_bwd: workspace too small");
+    WgradArgs a{dz, x, (float *)workspace, R, L, Cout, Cin, k, dil, dz_ld, x_ld, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    int splits = 1;
+    const int rc = wgrad_launch(a, (float *)workspace, workspace, workspace_bytes, (hipStream_t)stream, &splits);
+    if (rc) return rc;
+    return cer_weight_norm_bwd_partials((const float *)workspace, splits, v, g, norm, dv, dg, Cout, Cin * k, stream);
 }
 
 extern "C" int cer_conv2d_wgrad(const float *dz, const float *x, float *dw, int N, int H, int W, int Ho, int Wo, int Cout,

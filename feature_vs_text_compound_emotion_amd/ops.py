@@ -805,6 +805,37 @@ def weight_norm_fwd(v, g):
     return w, norm
 
 
+def weight_norm_fwd_packed(v, g):
+    """``weight_norm_fwd`` of a [Cout,Cin,k] filter plus, from the same launch, the packed forward weight [Cout,Kpad(k,1,Cin)] and
+    the flipped / transposed data-gradient weight [Cin,Kpad(k,1,Cout)] (``pack_conv_weight`` twice): (w, norm, wp, wt)."""
+    _dev_f32(v, "v")
+    _dev_f32(g, "g")
+    cout, cin, k = v.shape
+    w, norm = torch.empty_like(v), _empty((cout,), v)
+    wp, wt = _empty((cout, conv_kpad(k, 1, cin)), v), _empty((cin, conv_kpad(k, 1, cout)), v)
+    check(_lib.load().cer_weight_norm_fwd_packed(ptr(v), ptr(g), ptr(w), ptr(norm), ptr(wp), ptr(wt), cout, cin, k, current_stream()),
+          "cer_weight_norm_fwd_packed")
+    return w, norm, wp, wt
+
+
+def conv1d_wgrad_weight_norm_bwd(dz, x, seq_len, k, dil, v, g, norm):
+    """(dv, dg) of a weight-normed causal conv from dz [R,Cout] and the layer input x [R,Cin]: ``conv1d_wgrad`` +
+    ``weight_norm_bwd`` with the split-R partial sums folded inside the second kernel (two launches)."""
+    r, cout, dz_ld = _rows(dz, "dz")
+    r2, cin, x_ld = _rows(x, "x")
+    if r != r2:
+        raise ValueError("dz and x must have the same number of rows")
+    for t, n in ((v, "v"), (g, "g"), (norm, "norm")):
+        _dev_f32(t, n)
+    lib = _lib.load()
+    nbytes = max(lib.cer_conv_wgrad_workspace_bytes(r, cout, cin, k), cout * cin * k * 4)
+    ws = _empty((nbytes // 4,), dz)
+    dv, dg = torch.empty_like(v), torch.empty_like(g)       # (dg in g's [Cout,1,1] shape, as weight_norm_bwd returns it)
+    check(lib.cer_conv1d_wgrad_weight_norm_bwd(ptr(dz), dz_ld, ptr(x), x_ld, r, seq_len, cout, cin, k, dil, ptr(v), ptr(g), ptr(norm),
+                                               ptr(dv), ptr(dg), ptr(ws), nbytes, current_stream()), "cer_conv1d_wgrad_weight_norm_bwd")
+    return dv, dg
+
+
 def weight_norm_bwd(dw, v, g, norm):
     for t, n in ((dw, "dw"), (v, "v"), (g, "g"), (norm, "norm")):
         _dev_f32(t, n)

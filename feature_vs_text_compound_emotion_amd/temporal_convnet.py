@@ -59,19 +59,19 @@ class TemporalBlock(nn.Module):
         return ps
 
 
-def _conv_rows(x_rows, w_oihw3, bsz, length, k, dil, **kw):
-    """Causal conv over rows [B*L, Cin] with a [Cout,Cin,k] filter."""
+def _conv_rows(x_rows, w_oihw3, bsz, length, k, dil, packed=None, **kw):
+    """Causal conv over rows [B*L, Cin] with a [Cout,Cin,k] filter (``packed``: its packed form, if the caller has it)."""
     cout, cin, _ = w_oihw3.shape
-    wp = ops.pack_conv_weight(w_oihw3.view(cout, cin, k, 1))
+    wp = packed if packed is not None else ops.pack_conv_weight(w_oihw3.view(cout, cin, k, 1))
     y = ops.conv2d(x_rows.view(bsz, length, 1, cin), wp, k, 1, dil=(dil, 1), pad=((k - 1) * dil, 0),
                    out_hw=(length, 1), split_k=ops.auto_split_k(bsz * length, cout, cin * k), **kw)
     return y.view(bsz * length, cout)
 
 
-def _dgrad_rows(dz_rows, w_oihw3, bsz, length, k, dil, residual=None):
-    """dX of the causal conv: an anti-causal conv of dZ with the flipped, transposed filter."""
+def _dgrad_rows(dz_rows, w_oihw3, bsz, length, k, dil, residual=None, packed=None):
+    """dX of the causal conv: an anti-causal conv of dZ with the flipped, transposed filter (``packed``: that filter packed)."""
     cout, cin, _ = w_oihw3.shape
-    wt = ops.pack_conv_weight(w_oihw3.view(cout, cin, k, 1), flip=True, transpose=True)
+    wt = packed if packed is not None else ops.pack_conv_weight(w_oihw3.view(cout, cin, k, 1), flip=True, transpose=True)
     res = residual.view(bsz, length, 1, cin) if residual is not None else None
     y = ops.conv2d(dz_rows.view(bsz, length, 1, cout), wt, k, 1, dil=(dil, 1), pad=(0, 0), out_hw=(length, 1),
                    residual=res, split_k=ops.auto_split_k(bsz * length, cin, cout * k))
@@ -90,9 +90,10 @@ class TCNFunction(torch.autograd.Function):
             b1, g1, v1, b2, g2, v2 = params[pi:pi + 6]
             pi += 6
             m1, m2 = masks[lvl] if masks is not None else (None, None)
-            w1, n1 = ops.weight_norm_fwd(v1, g1)
-            w2, n2 = ops.weight_norm_fwd(v2, g2)
-            h1 = _conv_rows(x, w1, bsz, length, k, dil, bias=b1, act1=ops.ACT_LEAKY, mask=m1)
+            # weight-norm + both packed layouts of a conv in ONE launch (the weights change every step: 4 pack launches per level)
+            w1, n1, w1p, w1t = ops.weight_norm_fwd_packed(v1, g1)
+            w2, n2, w2p, w2t = ops.weight_norm_fwd_packed(v2, g2)
+            h1 = _conv_rows(x, w1, bsz, length, k, dil, packed=w1p, bias=b1, act1=ops.ACT_LEAKY, mask=m1)
             if has_ds:
                 dsw, dsb = params[pi:pi + 2]
                 pi += 2
@@ -100,9 +101,9 @@ class TCNFunction(torch.autograd.Function):
             else:
                 dsw, res = None, x
             a2 = torch.empty_like(h1)
-            out = _conv_rows(h1, w2, bsz, length, k, dil, bias=b2, act1=ops.ACT_LEAKY, mask=m2,
+            out = _conv_rows(h1, w2, bsz, length, k, dil, packed=w2p, bias=b2, act1=ops.ACT_LEAKY, mask=m2,
                              residual=res.view(bsz, length, 1, -1), act2=ops.ACT_LEAKY, aux=a2)
-            saved.append((x, h1, a2, out, w1, n1, w2, n2, m1, m2))
+            saved.append((x, h1, a2, out, w1, n1, w2, n2, m1, m2, w1t, w2t))
             x = out
         ctx.cfg, ctx.bsz, ctx.length, ctx.saved_levels, ctx.params = cfg, bsz, length, saved, params
         return x
@@ -121,15 +122,16 @@ class TCNFunction(torch.autograd.Function):
             k, dil, has_ds = cfg[lvl]
             o = offsets[lvl]
             b1, g1, v1, b2, g2, v2 = params[o:o + 6]
-            x, h1, a2, out, w1, n1, w2, n2, m1, m2 = ctx.saved_levels[lvl]
+            x, h1, a2, out, w1, n1, w2, n2, m1, m2, w1t, w2t = ctx.saved_levels[lvl]
             du, dz2 = ops.tblock_tail_bwd(dout, out, a2, m2)
             grads[o + 3] = ops.col_sum(dz2)
-            dv2, dg2 = ops.weight_norm_bwd(ops.conv1d_wgrad(dz2, h1, length, k, dil), v2, g2, n2)
+            # weight gradient -> (dv, dg): the weight-norm backward folds the split partial sums itself (no fold launch)
+            dv2, dg2 = ops.conv1d_wgrad_weight_norm_bwd(dz2, h1, length, k, dil, v2, g2, n2)
             grads[o + 4], grads[o + 5] = dg2, dv2
-            dh1 = _dgrad_rows(dz2, w2, bsz, length, k, dil)
+            dh1 = _dgrad_rows(dz2, w2, bsz, length, k, dil, packed=w2t)
             dz1 = ops.act_mask_bwd(dh1, h1, m1)
             grads[o + 0] = ops.col_sum(dz1)
-            dv1, dg1 = ops.weight_norm_bwd(ops.conv1d_wgrad(dz1, x, length, k, dil), v1, g1, n1)
+            dv1, dg1 = ops.conv1d_wgrad_weight_norm_bwd(dz1, x, length, k, dil, v1, g1, n1)
             grads[o + 1], grads[o + 2] = dg1, dv1
             if has_ds:
                 dsw = params[o + 6]
@@ -139,7 +141,7 @@ class TCNFunction(torch.autograd.Function):
             else:
                 dres = du
             need_dx = lvl > 0 or ctx.needs_input_grad[0]
-            dout = _dgrad_rows(dz1, w1, bsz, length, k, dil, residual=dres) if need_dx else None
+            dout = _dgrad_rows(dz1, w1, bsz, length, k, dil, residual=dres, packed=w1t) if need_dx else None
         return (dout, None, None, None, None, *grads)
 
 

@@ -244,6 +244,14 @@ int cer_frames_transform(const uint8_t *frames, int n_frames, int H, int W, cons
 int cer_weight_norm_fwd(const float *v, const float *g, float *w, float *norm, int rows, int E, void *stream);
 int cer_weight_norm_bwd(const float *dw, const float *v, const float *g, const float *norm,
                         float *dv, float *dg, int rows, int E, void *stream);
+/* The same forward for a [Cout][Cin][k] 1-D filter, writing in the same launch the two packed layouts the conv kernels read
+ * (cer_pack_conv_weight's): wp_fwd [Cout][cer_conv_kpad(k,1,Cin)] and the flipped, transposed data-gradient filter
+ * wp_dgrad [Cin][cer_conv_kpad(k,1,Cout)] -- the TCN (temporal_convolutional_model.py:24-38) re-normalises every step. */
+int cer_weight_norm_fwd_packed(const float *v, const float *g, float *w, float *norm, float *wp_fwd, float *wp_dgrad, int Cout,
+                               int Cin, int k, void *stream);
+/* The backward on the weight-gradient kernel's split partial slabs [splits][rows * E] (summed in the order 0 .. splits-1). */
+int cer_weight_norm_bwd_partials(const float *dw_parts, int splits, const float *v, const float *g, const float *norm, float *dv,
+                                 float *dg, int rows, int E, void *stream);
 
 /* Weight gradient of the causal dilated conv1d / linear layers:
  * dW[co][ci][j] = sum_r dZ[r][co] * X[r-(k-1-j)*dil][ci], rows never cross a length-L sequence.
@@ -254,6 +262,11 @@ int cer_weight_norm_bwd(const float *dw, const float *v, const float *g, const f
 size_t cer_conv_wgrad_workspace_bytes(long long R, int Cout, int Cin, int k);
 int cer_conv1d_wgrad(const float *dz, int dz_ld, const float *x, int x_ld, float *dw,
                      int R, int L, int Cout, int Cin, int k, int dil, void *workspace, size_t workspace_bytes, void *stream);
+/* cer_conv1d_wgrad of a weight-normed conv followed by its weight-norm backward, in two launches: (dv, dg) instead of dW.
+ * workspace: max(cer_conv_wgrad_workspace_bytes(R, Cout, Cin, k), Cout * Cin * k * 4) bytes. */
+int cer_conv1d_wgrad_weight_norm_bwd(const float *dz, int dz_ld, const float *x, int x_ld, int R, int L, int Cout, int Cin, int k,
+                                     int dil, const float *v, const float *g, const float *norm, float *dv, float *dg,
+                                     void *workspace, size_t workspace_bytes, void *stream);
 
 /* 2-D weight gradient (encoder units released for training, reference base/parameter_control.py:55-103):
  * dW[co][ci][kh][kw] = sum over output pixels (n,ho,wo) of dZ[n,ho,wo,co] * X[n, ho*stride-pad_t+kh, wo*stride-pad_l+kw, ci]

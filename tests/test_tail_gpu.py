@@ -40,6 +40,34 @@ def test_weight_norm_fwd_bwd():
     _close(dg, g.grad)
 
 
+@pytest.mark.parametrize("cout,cin,k", [(48, 64, 5), (32, 40, 5), (512, 768, 5), (5, 7, 3)])
+def test_weight_norm_fwd_packed_equals_weight_norm_then_two_packs(cout, cin, k):
+    """One launch = weight-norm + the packed forward filter + the flipped / transposed data-gradient filter, bit for bit what the
+    three separate launches produce (zero padding included)."""
+    ops = _ops()
+    g_ = torch.Generator().manual_seed(cout + cin)
+    v, g = torch.randn(cout, cin, k, generator=g_).cuda(), (torch.rand(cout, 1, 1, generator=g_) + 0.5).cuda()
+    w0, n0 = ops.weight_norm_fwd(v, g)
+    w, n, wp, wt = ops.weight_norm_fwd_packed(v, g)
+    assert torch.equal(w, w0) and torch.equal(n, n0)
+    assert torch.equal(wp, ops.pack_conv_weight(w0.view(cout, cin, k, 1)))
+    assert torch.equal(wt, ops.pack_conv_weight(w0.view(cout, cin, k, 1), flip=True, transpose=True))
+
+
+@pytest.mark.parametrize("cout,cin,k,dil,bsz,length", [(64, 128, 5, 4, 3, 16), (32, 32, 5, 2, 32, 32), (512, 768, 5, 1, 32, 32)])
+def test_wgrad_into_weight_norm_backward_equals_the_three_launches(cout, cin, k, dil, bsz, length):
+    """conv1d_wgrad_weight_norm_bwd: the weight-norm backward sums the weight-gradient kernel's split partial slabs itself, in
+    the order the fold kernel used -- (dv, dg) bit-identical to conv1d_wgrad + weight_norm_bwd."""
+    ops = _ops()
+    g_ = torch.Generator().manual_seed(cout + cin + k)
+    dz, x = torch.randn(bsz * length, cout, generator=g_).cuda(), torch.randn(bsz * length, cin, generator=g_).cuda()
+    v, g = torch.randn(cout, cin, k, generator=g_).cuda(), (torch.rand(cout, 1, 1, generator=g_) + 0.5).cuda()
+    _, norm = ops.weight_norm_fwd(v, g)
+    dv0, dg0 = ops.weight_norm_bwd(ops.conv1d_wgrad(dz, x, length, k, dil), v, g, norm)
+    dv, dg = ops.conv1d_wgrad_weight_norm_bwd(dz, x, length, k, dil, v, g, norm)
+    assert torch.equal(dv, dv0) and torch.equal(dg, dg0)
+
+
 @pytest.mark.parametrize("cout,cin,k,dil,bsz,length", [(64, 128, 5, 4, 3, 16), (7, 224, 1, 1, 2, 8),
                                                         (96, 32, 1, 1, 2, 8), (40, 72, 5, 1, 2, 8)])
 def test_conv1d_wgrad(cout, cin, k, dil, bsz, length):
