@@ -510,7 +510,11 @@ template <int NARROW> __device__ __forceinline__ void unpack8_n16(const uint4 q,
 // One pixel x 8 consecutive couts (c .. c + 7 < Cout) of a specialised mode.  row: the output row (the pixel, or its
 // space-to-depth position); cs: the pixel's border case for the bias9 modes; aa / bb: PReLU slopes and the interior (or plain)
 // bias of the 8 couts.  NARROW: CER_STORE_BF16 / CER_STORE_F16 for the *_N16 modes, ignored otherwise.
-template <int MODE, int NARROW>
+// BORDER = false: the caller knows (wave-uniformly) that no lane of the wave holds a border pixel -- the bias9 modes then contain
+// no load at all.  It matters: the compiler places the s_waitcnt vmcnt(0) of the border rows' loads AFTER the divergent branch,
+// where every wave executes it, loads or not -- and on gfx9 that one counter also covers the stores, so every 16-byte store of the
+// epilogue waited for the previous one to be acknowledged (and for the window DMA in flight).
+template <int MODE, int NARROW, bool BORDER = true>
 __device__ __forceinline__ void epi_direct8(const ConvArgs &p, const float (&aa)[8], const float (&bb)[8], size_t row, int c, int cs,
                                             const float (&v)[8]) {
     static_assert(MODE != EPI_GENERIC, "specialised modes only");
@@ -522,10 +526,12 @@ __device__ __forceinline__ void epi_direct8(const ConvArgs &p, const float (&aa)
         float b[8];
 #pragma unroll
         for (int t = 0; t < 8; ++t) b[t] = bb[t];
-        if (cs != 4) {   // a border pixel: its own bias row (L1 / L2 hits; one lane in eight at most on the 16x16 patches)
-            const float4 q0 = *reinterpret_cast<const float4 *>(p.bias9 + (size_t)cs * p.Cout + c);
-            const float4 q1 = *reinterpret_cast<const float4 *>(p.bias9 + (size_t)cs * p.Cout + c + 4);
-            b[0] = q0.x; b[1] = q0.y; b[2] = q0.z; b[3] = q0.w; b[4] = q1.x; b[5] = q1.y; b[6] = q1.z; b[7] = q1.w;
+        if constexpr (BORDER) {
+            if (cs != 4) {   // a border pixel: its own bias row (L1 / L2 hits; one lane in eight at most on the 16x16 patches)
+                const float4 q0 = *reinterpret_cast<const float4 *>(p.bias9 + (size_t)cs * p.Cout + c);
+                const float4 q1 = *reinterpret_cast<const float4 *>(p.bias9 + (size_t)cs * p.Cout + c + 4);
+                b[0] = q0.x; b[1] = q0.y; b[2] = q0.z; b[3] = q0.w; b[4] = q1.x; b[5] = q1.y; b[6] = q1.z; b[7] = q1.w;
+            }
         }
 #pragma unroll
         for (int t = 0; t < 8; ++t) {
@@ -614,7 +620,13 @@ __device__ __forceinline__ void epi_direct_stores(const ConvArgs &p, const ACC (
                         s1[j][t] += v[t];
                         s2[j][t] += v[t] * v[t];
                     }
-                    epi_direct8<MODE, NARROW>(p, aa, bb, px[b].row, c, px[b].cs, v);
+                    if constexpr (MODE == EPI_B9_PRELU_SPLIT || MODE == EPI_B9_PRELU_N16) {
+                        // (wave-uniform: does any lane of the wave hold a border pixel of this pixel tile?)
+                        if (__ballot(px[b].cs != 4) != 0ull) epi_direct8<MODE, NARROW, true>(p, aa, bb, px[b].row, c, px[b].cs, v);
+                        else epi_direct8<MODE, NARROW, false>(p, aa, bb, px[b].row, c, 4, v);
+                    } else {
+                        epi_direct8<MODE, NARROW, false>(p, aa, bb, px[b].row, c, px[b].cs, v);
+                    }
                 }
             });
         }

@@ -142,6 +142,7 @@ __global__ __launch_bounds__(512, 2) void conv_n16_p64_kernel(ConvArgs p, PatchG
                 bf[set][b] = *reinterpret_cast<const n_u32x4 *>(Xb + kh * (WW * 128) + ((bcol[kw] + b * WP * WW * 128) ^ (kk << 6)));
         };
         read_half(IdxC<0>{}, 0);
+        __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);      // (the hints below count DS reads from here: these eight first)
         static_for<18>([&](auto Hh) {
             constexpr int h = decltype(Hh)::v, set = h & 1;
             if constexpr (h < 17) read_half(IdxC<h + 1>{}, set ^ 1);
@@ -156,12 +157,12 @@ __global__ __launch_bounds__(512, 2) void conv_n16_p64_kernel(ConvArgs p, PatchG
                         acc[a][b] = mfma_n16<F16>(af[set][a], bf[set][b], acc[a][b]);
                     }
                 }
+            // issue order: the next half tap's eight fragment reads FIRST (a whole half tap of MFMAs covers their latency), then the
+            // 16 MFMAs.  (Reads spread between the MFMA groups came out one group late: the compiler's lgkmcnt(1..4) before every
+            // group of four MFMAs waited for reads it had just issued -- 5.0 us per K phase for 2.7 us of MFMAs in the stamps.)
             if constexpr (h < 17) {
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
-                    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-                }
+                __builtin_amdgcn_sched_group_barrier(0x100, 8, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 16, 0);
             }
         });
     };
@@ -209,7 +210,13 @@ __global__ __launch_bounds__(512, 2) void conv_n16_p64_kernel(ConvArgs p, PatchG
                         s2[j][e] += v[e] * v[e];
                     }
                 }
-                epi_direct8<MODE, NARROW>(p, aa[j], bb[j], (size_t)(p.y_s2d ? s2d_row(m, gy, gx, p.W) : m), c, cs, v);
+                const size_t orow = (size_t)(p.y_s2d ? s2d_row(m, gy, gx, p.W) : m);
+                if constexpr (MODE == EPI_B9_PRELU_N16) {   // (border rows are loaded only in waves that hold a border pixel: conv_common.h)
+                    if (__ballot(cs != 4) != 0ull) epi_direct8<MODE, NARROW, true>(p, aa[j], bb[j], orow, c, cs, v);
+                    else epi_direct8<MODE, NARROW, false>(p, aa[j], bb[j], orow, c, 4, v);
+                } else {
+                    epi_direct8<MODE, NARROW, false>(p, aa[j], bb[j], orow, c, cs, v);
+                }
             });
             __builtin_amdgcn_sched_barrier(0);
             // the next window has landed; at least NST younger operations (this phase's stores) may stay in flight

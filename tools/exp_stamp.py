@@ -41,17 +41,18 @@ PATCHES = [
      "                __builtin_amdgcn_s_barrier();\n                if (cc == 0 && tap == 0) STAMP(4);\n"
      "            }\n            constexpr int ntap = (tap + 2) % 9, nring = (tap + 2) % 3;\n"
      "            const int ncc = cc + (tap + 2 >= 9 ? 1 : 0);\n            const unsigned char *Wr = smem + (tap % 3) * WSLICE;"),
-    ("(zero fills: they return at once)\n", "(zero fills: they return at once)\n    STAMP(5);\n    const unsigned dbgf = STAMPED && cer_dbg_buf ? (unsigned)cer_dbg_buf[0] : 0u;\n"),
-    # ablations: bit 1 of buf[0] = no MFMAs, bit 2 = no output stores, bit 3 = no window fetch (LDS garbage: timing only)
-    ("        epi_dispatch(emode, [&](auto MODE_) {\n            constexpr int MODE = decltype(MODE_)::v;\n            if constexpr (MODE != EPI_GENERIC) {\n                static_for<TC / 2>([&](auto J) {\n                    constexpr int j = decltype(J)::v;\n                    const int c = cw + j * 32 + kg * 8;\n                    float aa[8], bb[8];\n                    epi_direct_consts<MODE>(p, c, aa, bb);\n                    if (c + 7 < p.Cout) {\n                        static_for<TP>([&](auto B) {\n                            constexpr int b = decltype(B)::v;\n                            const int gy",
-     "        epi_dispatch(emode, [&](auto MODE_) {\n            constexpr int MODE = decltype(MODE_)::v;\n            if constexpr (MODE != EPI_GENERIC) {\n                static_for<TC / 2>([&](auto J) {\n                    constexpr int j = decltype(J)::v;\n                    const int c = cw + j * 32 + kg * 8;\n                    float aa[8], bb[8];\n                    epi_direct_consts<MODE>(p, c, aa, bb);\n                    if (c + 7 < p.Cout && !(dbgf & 4u)) {\n                        static_for<TP>([&](auto B) {\n                            constexpr int b = decltype(B)::v;\n                            const int gy"),
-    ("        if constexpr (PP) {\n            if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary\n        }\n"
-     "        if (p.stats) {\n",
-     "        if (dbgf & 1u) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); }\n        STAMP(6);\n"
-     "        if constexpr (PP) {\n            if (wc == 0) __builtin_amdgcn_s_barrier();   // pairs with group 1's last phase boundary\n        }\n"
-     "        if (p.stats) {\n"),
-    ("                p.stats[((size_t)patch * 2 + 1) * p.Cout + c0 + tid] = t2;\n            }\n        }\n        return;\n",
-     "                p.stats[((size_t)patch * 2 + 1) * p.Cout + c0 + tid] = t2;\n            }\n        }\n        DUMP();\n        return;\n"),
+    ("(zero fills: they return at once)\n", "(zero fills: they return at once)\n    STAMP(5);\n"),
+    # ablations: bit 1 of buf[0] = no MFMAs, bit 2 = no output stores (timing only)
+    ("                for (int a = 0; a < TC; ++a) acc[a][b] = mfma_n16<F16>(af[kk][a], bf[g], acc[a][b]);\n            });\n            // issue order",
+     "                for (int a = 0; a < TC; ++a) if (!(dbgf & 2u)) acc[a][b] = mfma_n16<F16>(af[kk][a], bf[g], acc[a][b]);\n            });\n            // issue order"),
+    ("    const int cin_steps = p.cin_steps;\n\n    // ---- DMA assignment ----",
+     "    const int cin_steps = p.cin_steps;\n    const unsigned dbgf = STAMPED && cer_dbg_buf ? (unsigned)cer_dbg_buf[0] : 0u;\n\n    // ---- DMA assignment ----"),
+    # direct path (patch kernel: the first occurrence): stores skipped on request, stamp after them, dump before the return
+    ("            if constexpr (MODE != EPI_GENERIC) epi_direct_stores<MODE, NARROW, TC, TP>(p, acc, c0 + wc * TC * 16, kg, epx, s1, s2);\n        });\n",
+     "            if constexpr (MODE != EPI_GENERIC) { if (!(dbgf & 4u)) epi_direct_stores<MODE, NARROW, TC, TP>(p, acc, c0 + wc * TC * 16, kg, epx, s1, s2); }\n        });\n"
+     "        if (dbgf & 1u) { asm volatile(\"s_waitcnt vmcnt(0)\" ::: \"memory\"); }\n        STAMP(6);\n"),
+    ("        if (p.stats) epi_direct_stats<TC, WP, BN>(p, s1, s2, reinterpret_cast<float *>(smem_n16p), wp, wc, kg, l15, tid, c0, (size_t)patch);\n        return;\n",
+     "        if (p.stats) epi_direct_stats<TC, WP, BN>(p, s1, s2, reinterpret_cast<float *>(smem_n16p), wp, wc, kg, l15, tid, c0, (size_t)patch);\n        DUMP();\n        return;\n"),
 ]
 
 

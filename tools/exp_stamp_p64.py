@@ -1,5 +1,5 @@
-"""In-kernel timeline of the persistent narrow patch kernel (tile 79, conv_n16_p64.hip): per wave and patch, s_memrealtime at
-the top of the patch, after its 18 half taps (before the vmcnt wait), after the wait, after the block barrier.
+"""In-kernel timeline of the persistent narrow patch kernel (tile 79, conv_n16_p64.hip): per wave and phase, s_memrealtime at the
+top of the phase, after its work (K phase: 18 half taps; E phase: window DMA, epilogue, the vmcnt wait), after the block barrier.
     python tools/exp_stamp_p64.py build && gpurun -- python tools/exp_stamp_p64.py run"""
 import argparse
 import ctypes
@@ -15,16 +15,11 @@ NIT = 64
 
 PATCHES = [
     ("namespace cer {\n\nnamespace {", "namespace cer {\n__device__ unsigned long long *cer_dbg_buf = nullptr;\n"
-     "#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (cer_dbg_buf && it < 64 && lane == 0) "
-     "cer_dbg_buf[16 + ((size_t)(blockIdx.x * 4 + wave) * 64 + it) * 4 + i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)\n\nnamespace {"),
-    ("        unsigned xo[XPW];\n        if (has_next) window_offsets(nxt, xo);", "        STAMP(0);\n        unsigned xo[XPW];\n        if (has_next) window_offsets(nxt, xo);"),
-    ("    const int emode = epi_mode(p);\n", "    const int emode = epi_mode(p);\n    const unsigned dbgf = cer_dbg_buf ? (unsigned)cer_dbg_buf[0] : 0u;\n"),
-    ("            if constexpr (HAS_PREV && h >= 10) {\n", "            if (HAS_PREV && h >= 10 && !(dbgf & 1u)) {\n"),
-    ("                if (has_next) {\n#pragma unroll\n                    for (int i = first; i < first + cnt; ++i) issue_x(i, nxt, xo, cur ^ 1);",
-     "                if (has_next && !(dbgf & 2u)) {\n#pragma unroll\n                    for (int i = first; i < first + cnt; ++i) issue_x(i, nxt, xo, cur ^ 1);"),
-    ("        // window `nxt` has landed (the stores", "        STAMP(1);\n        // window `nxt` has landed (the stores"),
-    ("        __builtin_amdgcn_s_barrier();\n        __builtin_amdgcn_sched_barrier(0);\n        if constexpr (HAS_PREV && STATS) stats_final(it & 1, prv);",
-     "        STAMP(2);\n        __builtin_amdgcn_s_barrier();\n        STAMP(3);\n        if constexpr (HAS_PREV && STATS) stats_final(it & 1, prv);"),
+     "#define STAMP(i) do { __builtin_amdgcn_sched_barrier(0); if (cer_dbg_buf && ph < 64 && lane == 0) "
+     "cer_dbg_buf[16 + ((size_t)(blockIdx.x * 8 + wave) * 64 + ph) * 4 + i] = __builtin_amdgcn_s_memrealtime(); __builtin_amdgcn_sched_barrier(0); } while (0)\n\nnamespace {"),
+    ("            const bool kph = ((ph ^ grp) & 1) == 0;\n", "            STAMP(0);\n            const bool kph = ((ph ^ grp) & 1) == 0;\n"),
+    ("            __builtin_amdgcn_sched_barrier(0);\n            __builtin_amdgcn_s_barrier();\n            __builtin_amdgcn_sched_barrier(0);\n        }\n        if constexpr (STATS) {\n            // the block's totals",
+     "            STAMP(1);\n            __builtin_amdgcn_s_barrier();\n            STAMP(2);\n        }\n        if constexpr (STATS) {\n            // the block's totals"),
 ]
 
 
@@ -65,8 +60,7 @@ def run(a):
     dt = torch.bfloat16
     x = ops.to_n16(torch.randn(a.frames, h, h, cin, device="cuda"), dt)
     w = ops.to_n16(torch.randn(cout, ops.conv_kpad(3, 3, cin), device="cuda") * 0.02, dt)
-    buf = torch.zeros(16 + 256 * 4 * NIT * 4, dtype=torch.int64, device="cuda")
-    buf[0] = a.flags
+    buf = torch.zeros(16 + 256 * 8 * NIT * 4, dtype=torch.int64, device="cuda")
     assert raw.cer_dbg_set_buf(ctypes.c_void_p(buf.data_ptr())) == 0
     run_ = lambda: ops.conv2d_n16(x, w, 3, 3, stride=1, pad=(1, 1), tile=79, want_stats=bool(a.stats))  # noqa: E731
     for _ in range(2):
@@ -81,21 +75,20 @@ def run(a):
     ms = e0.elapsed_time(e1)
     flops = 2.0 * a.frames * h * h * cout * cin * 9
     print(f"launch {ms:.3f} ms  {flops / ms / 1e9:.0f} TF/s")
-    t = buf[16:].view(256, 4, NIT, 4).cpu().numpy().astype(np.float64) * 0.01
-    ok = t[:, :, 2:NIT - 1, :]                                   # steady state: patches 2 .. 62
-    k = ok[..., 1] - ok[..., 0]
-    wv = ok[..., 2] - ok[..., 1]
-    bar = ok[..., 3] - ok[..., 2]
-    nxt = t[:, :, 3:NIT, 0] - t[:, :, 2:NIT - 1, 3]
-    per = t[:, :, 3:NIT, 0] - t[:, :, 2:NIT - 1, 0]
-    for nm, d in (("18 half taps (+ DMA issue, epilogue of the previous patch)", k), ("vmcnt wait (next window)", wv), ("block barrier", bar),
-                  ("barrier -> next patch's top (statistics, loop)", nxt), ("patch period", per)):
-        print(f"{nm:62s} mean {d.mean():6.2f} us  p10 {np.percentile(d, 10):6.2f}  p50 {np.percentile(d, 50):6.2f}  p90 {np.percentile(d, 90):6.2f}")
-    b = 100
-    print("block 100, per wave: top, taps done, window landed, barrier passed (us from patch 2's top of wave 0)")
-    base = t[b, 0, 2, 0]
-    for it in range(2, 8):
-        print("  " + " | ".join(" ".join(f"{v - base:7.2f}" for v in t[b, wv_, it]) for wv_ in range(4)))
+    t = buf[16:].view(256, 8, NIT, 4).cpu().numpy().astype(np.float64) * 0.01     # [block][wave][phase][stamp] in us
+    ph = np.arange(8, NIT - 2)                                   # steady state
+    for g in (0, 1):
+        w = t[:, 4 * g:4 * g + 4]
+        kph = ph[(ph % 2) == g]                                  # the group's K phases; its E phases follow
+        eph = kph + 1
+        kwork = w[:, :, kph, 1] - w[:, :, kph, 0]
+        ework = w[:, :, eph, 1] - w[:, :, eph, 0]
+        kbar = w[:, :, kph, 2] - w[:, :, kph, 1]
+        ebar = w[:, :, eph, 2] - w[:, :, eph, 1]
+        print(f"group {g}: K phase (18 half taps) {kwork.mean():5.2f} us, then barrier wait {kbar.mean():5.2f};  "
+              f"E phase (window DMA + epilogue + vmcnt) {ework.mean():5.2f} us, then barrier wait {ebar.mean():5.2f}")
+    per = t[:, 0, 10:NIT - 2, 0] - t[:, 0, 9:NIT - 3, 0]
+    print(f"phase period {per.mean():5.2f} us = one patch per CU (three stamps per phase cost ~0.1 us each)")
 
 
 if __name__ == "__main__":
@@ -105,6 +98,5 @@ if __name__ == "__main__":
     ap.add_argument("--hw", type=int, default=224)
     ap.add_argument("--cout", type=int, default=64)
     ap.add_argument("--stats", type=int, default=0)
-    ap.add_argument("--flags", type=int, default=0)
     a = ap.parse_args()
     build() if a.cmd == "build" else run(a)
