@@ -167,3 +167,24 @@ def test_space_to_depth_weight_order_and_layout_describe_the_stride2_conv():
             sl = img[:, kh:kh + h // 2, kw:kw + w // 2]
             out += torch.einsum("nhwc,oc->nhwo", sl, wt[:, :, tap // 3, tap % 3])
     assert (out - ref).abs().max().item() < 1e-5
+
+
+def test_reciprocal_division_of_the_kernel_prologues_is_exact():
+    """csrc/conv_common.h FastDiv / fdiv (block -> patch / tile, pixel -> image row / column in the window and patch kernels):
+    magic = 2^32 / d + 1, q = umulhi(x, magic), q -= (q * d > x).  The arithmetic restated on 64-bit integers: exact for every
+    x < 2^31 (M = N H W is an int) and every divisor the launchers build, and q * d never wraps 32 bits."""
+    rng = np.random.default_rng(0)
+    divisors = list(range(1, 300)) + [392, 784, 3136, 12544, 50176, 65535, 65536, 100003, 2 ** 20 + 7, 2 ** 24 - 3, 2 ** 30 + 1]
+    for d in divisors:
+        magic = np.uint64(((1 << 32) // d + 1) & 0xffffffff)
+        mult = np.arange(1, 3000, dtype=np.uint64) * np.uint64(d)
+        xs = np.concatenate([rng.integers(0, 2 ** 31, 20000, dtype=np.uint64), np.arange(0, 5000, dtype=np.uint64),
+                             mult % np.uint64(2 ** 31), (mult - np.uint64(1)) % np.uint64(2 ** 31),
+                             np.array([2 ** 31 - 1, 2 ** 31 - 2], dtype=np.uint64)])
+        if d == 1:
+            q = xs.copy()
+        else:
+            q = (xs * magic) >> np.uint64(32)
+            assert (q * np.uint64(d) < np.uint64(2 ** 32)).all()          # the 32-bit product of the correction step does not wrap
+            q = q - (q * np.uint64(d) > xs)
+        assert (q == xs // np.uint64(d)).all(), d
