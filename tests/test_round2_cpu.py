@@ -188,3 +188,18 @@ def test_reciprocal_division_of_the_kernel_prologues_is_exact():
             assert (q * np.uint64(d) < np.uint64(2 ** 32)).all()          # the 32-bit product of the correction step does not wrap
             q = q - (q * np.uint64(d) > xs)
         assert (q == xs // np.uint64(d)).all(), d
+
+
+def test_direct_epilogue_weight_row_permutation_makes_tile_pairs_contiguous():
+    """csrc/conv_common.h epi_cout_of_row: MFMA tile a, tile row 4 kg + r of a wave's 16 TC weight rows holds cout
+    32 (a / 2) + 8 kg + 4 (a % 2) + r.  A bijection on the wave's span, and the eight accumulators a lane holds of a tile pair
+    (two tiles x four rows) are eight CONSECUTIVE couts starting at 32 j + 8 kg -- what lets the epilogue store 16 bytes per lane."""
+    def cout_of_row(rho):
+        return ((rho >> 5) << 5) + (((rho >> 2) & 3) << 3) + (((rho >> 4) & 1) << 2) + (rho & 3)
+    for tc in (2, 4, 8):
+        span = 16 * tc
+        assert sorted(cout_of_row(r) for r in range(span)) == list(range(span))
+        for j in range(tc // 2):
+            for kg in range(4):
+                got = [cout_of_row(16 * (2 * j + half) + 4 * kg + r) for half in (0, 1) for r in range(4)]
+                assert got == list(range(32 * j + 8 * kg, 32 * j + 8 * kg + 8))
